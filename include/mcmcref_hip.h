@@ -1,0 +1,168 @@
+/*
+ * mcmcref_hip.h -- C ABI of libmcmcref_hip.so, the MI355X (gfx950) implementation of the
+ * draw-vs-reference statistics hot path of StefanSko/mcmc-db (`mcmc_ref` 0.1.4).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A Python
+ * host binds it with ctypes (mcmc-db_amd/mcmc_ref_hip/_ffi.py; the reference-side stub is
+ * shown in INTEGRATION.md).  Each entry point names the reference interface it replaces
+ * (file:line relative to the reference repo root).
+ *
+ * Conventions
+ *   - every function returns MCR_OK (0) or a negative MCR_E* code and never throws/aborts;
+ *     mcr_last_error(ctx) returns a human-readable message for the last failure on ctx.
+ *   - the caller owns every host buffer; the library owns all device scratch in mcr_ctx.
+ *   - one mcr_ctx == one GPU + one HIP stream.  Calls on one ctx must be serialised by the
+ *     caller; different ctxs are independent (one process per GPU, or several ctxs in one).
+ *   - tensors are described by element strides (stride_c, stride_n, stride_p), so both the
+ *     Arrow column layout [P][C][N] and `Draws.to_numpy` layout [C][N][P] (src/mcmc_ref/draws.py:28-29)
+ *     are accepted without a host-side copy.
+ *   - dtype: MCR_F64 (the reference's only dtype) or MCR_F32 (widened to f64 on load).
+ *   - NaN/Inf in the draws are rejected with MCR_ENONFINITE (the reference's behaviour for
+ *     them is undefined: sort order with NaN).
+ */
+#ifndef MCMCREF_HIP_H
+#define MCMCREF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCR_VERSION 100 /* 0.1.0 */
+
+#define MCR_OK 0
+#define MCR_EINVAL (-1)         /* null pointer, negative size, unsupported dtype/quantile count */
+#define MCR_EMINCHAINS (-2)     /* C < min_chains: "... require at least k chains; got m chain(s)"
+                                   (src/mcmc_ref/diagnostics.py:25-28, 49-52, 65-68) */
+#define MCR_EMINCHAINS_ARG (-3) /* min_chains < 1: "min_chains must be >= 1; got k" (diagnostics.py:88-90) */
+#define MCR_ENONFINITE (-4)     /* NaN/Inf found in the draws */
+#define MCR_EHIP (-5)           /* HIP runtime error (message has the hipError string) */
+#define MCR_ENOMEM (-6)         /* host or device allocation failed */
+#define MCR_ENODEVICE (-7)      /* no usable HIP device / bad device index */
+#define MCR_ECOMM (-8)          /* RCCL error (multi-GPU gather) */
+
+#define MCR_F64 0
+#define MCR_F32 1
+
+#define MCR_MAX_QUANTILES 32
+
+typedef struct mcr_ctx mcr_ctx;
+
+/* Per-parameter results, struct-of-arrays, caller allocated.  Every non-NULL array has P
+ * entries, except q (P * n_q, row-major [p][k]) and q_lo (n_q).  NULL members are skipped.
+ *
+ *  mean, std, q   Backend.stats(): pooled mean, population std (ddof=0), linear-interpolated
+ *                 quantiles (src/mcmc_ref/backends.py:14-24, backends_arrow.py:36-51,
+ *                 backends_numpy.py:40-47).  q_lo[k] = floor((M-1)*q_k): the order-statistic
+ *                 index (integer, bit-exact gate).
+ *  median         statistics.median of the pooled draws, the fold point (diagnostics.py:97).
+ *  rhat           split_rhat(): max(rhat_bulk, rhat_tail) with Python max() NaN ordering
+ *                 (diagnostics.py:13-40); rhat_bulk / rhat_tail are its two operands.
+ *  ess_bulk/tail  ess_bulk(), ess_tail() (diagnostics.py:43-73).
+ *  lag_bulk/tail  number of autocorrelation terms accumulated before the first negative rho
+ *                 (diagnostics.py:171-177) -- integer, bit-exact gate.
+ */
+typedef struct mcr_summary {
+    double* mean;
+    double* std;
+    double* q;
+    double* median;
+    double* rhat;
+    double* rhat_bulk;
+    double* rhat_tail;
+    double* ess_bulk;
+    double* ess_tail;
+    int64_t* lag_bulk;
+    int64_t* lag_tail;
+    int64_t* q_lo;
+} mcr_summary;
+
+/* Accumulated HIP-event time of one kernel since profiling was last reset. */
+typedef struct mcr_kernel_time {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} mcr_kernel_time;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+int mcr_version(void);
+int mcr_device_count(void);
+/* Creates a context bound to HIP device `device` (own non-blocking stream, lazily grown
+ * workspace).  Fails with MCR_ENODEVICE when no GPU is present: there is no CPU fallback. */
+int mcr_init(int device, mcr_ctx** out);
+void mcr_free(mcr_ctx* ctx);
+const char* mcr_last_error(const mcr_ctx* ctx); /* ctx may be NULL: last mcr_init failure */
+/* Upper bound for device scratch (bytes); parameters are processed in chunks that fit.
+ * Default: MCR_WORKSPACE_MB env or 8192 MiB. */
+int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes);
+
+/* ---- device memory plumbing (for device-resident benchmarking and pipelines) --------- */
+int mcr_dev_alloc(mcr_ctx* ctx, size_t bytes, void** dptr);
+int mcr_dev_free(mcr_ctx* ctx, void* dptr);
+int mcr_memcpy_h2d(mcr_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
+int mcr_memcpy_d2h(mcr_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+int mcr_sync(mcr_ctx* ctx);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* Everything the reference computes per parameter over a (C chains x N draws x P params)
+ * tensor, in one call: replaces the per-parameter Python loops of
+ *   convert._compute_diagnostics            (src/mcmc_ref/convert.py:134-147)
+ *   reference.diagnostics_for_model         (src/mcmc_ref/reference.py:92-104)
+ *   Backend.stats                            (src/mcmc_ref/backends_arrow.py:36-51)
+ * `draws` is a HOST pointer (copied to the device inside the call). Synchronous. */
+int mcr_summarize(mcr_ctx* ctx, const void* draws, int dtype, int64_t C, int64_t N, int64_t P,
+                  int64_t stride_c, int64_t stride_n, int64_t stride_p, int min_chains,
+                  const double* quantiles, int n_q, mcr_summary* out);
+/* Same with `draws` already resident in this ctx's device memory.  Synchronous. */
+int mcr_summarize_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N,
+                      int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
+                      int min_chains, const double* quantiles, int n_q, mcr_summary* out);
+/* Asynchronous form: enqueues the whole pipeline on the ctx stream and returns; results
+ * land in `out` (which must stay valid) when mcr_summarize_wait() returns.  At most
+ * MCR_MAX_INFLIGHT enqueues may be outstanding per ctx. */
+#define MCR_MAX_INFLIGHT 4
+int mcr_summarize_enqueue(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N,
+                          int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
+                          int min_chains, const double* quantiles, int n_q, mcr_summary* out);
+int mcr_summarize_wait(mcr_ctx* ctx);
+
+/* diagnostics.split_rhat / ess_bulk / ess_tail for ONE parameter given as possibly ragged
+ * chains (src/mcmc_ref/diagnostics.py:13-73): `pooled` holds the chains back to back, chain c
+ * is pooled[chain_off[c] .. chain_off[c+1]).  Host pointers.  out arrays have 1 entry.
+ * Optional debug outputs (host, length chain_off[C], may be NULL): z_bulk / z_tail =
+ * _rank_normalize(x) / _rank_normalize(_fold_chains(x)) (diagnostics.py:93-133), rank_bulk /
+ * rank_tail = the average ranks (exact multiples of 0.5). */
+int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain_off, int C,
+                        int min_chains, mcr_summary* out, double* z_bulk, double* z_tail,
+                        double* rank_bulk, double* rank_tail);
+
+/* compare.compute_basic_stats (src/mcmc_ref/compare.py:58-64): mean and population std of n
+ * host values; n == 0 gives NaN, NaN.  Also the streaming "moments" kernel (HBM-bound). */
+int mcr_basic_stats(mcr_ctx* ctx, const void* values, int dtype, int64_t n, double* mean,
+                    double* std);
+/* Pooled mean / population std per parameter of a device-resident tensor (one HBM pass). */
+int mcr_moments_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N,
+                    int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
+                    double* mean, double* std);
+/* compare.compare_stats inner arithmetic (src/mcmc_ref/compare.py:38-43) on n (ref, actual)
+ * pairs: rel = |a-r| / max(|r|, 1e-12), pass = rel <= tol (NaN -> 0).  Host pointers. */
+int mcr_compare(mcr_ctx* ctx, const double* ref, const double* actual, int64_t n, double tol,
+                double* rel_error, uint8_t* passed);
+
+/* ---- measurement ------------------------------------------------------------------- */
+/* When on, every kernel launch is bracketed by HIP events on the ctx stream. */
+int mcr_profile_enable(mcr_ctx* ctx, int on);
+int mcr_profile_reset(mcr_ctx* ctx);
+/* Synchronises, resolves the events and fills up to `max` entries; *n = entries available. */
+int mcr_profile_get(mcr_ctx* ctx, mcr_kernel_time* out, int max, int* n);
+/* Fills a device buffer with the synthetic stress tensor of SURVEY.md 8(d) C4 (iid
+ * N(p, sigma_p), counter-based, layout [P][C][N]) without touching the host. */
+int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P,
+                       uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMCREF_HIP_H */

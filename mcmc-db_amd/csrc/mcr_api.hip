@@ -1,0 +1,853 @@
+// mcr_api.hip -- the C ABI of libmcmcref_hip.so (see include/mcmcref_hip.h) and the host-side
+// launch logic: workspace carving, parameter chunking, async result slots, HIP-event profiling.
+// Plain HIP runtime only: no torch, no hipify, no compatibility layers.
+#include "../../include/mcmcref_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mcr_kernels.hpp"
+
+using namespace mcr;
+
+namespace {
+
+constexpr int kSortNT = 256, kSortVT = 16, kTile = kSortNT * kSortVT;
+constexpr size_t kSortLds = (size_t)(kTile + kTile / 16) * 12 + 64;
+constexpr int kMaxChains = 256;
+constexpr int kMaxGridY = 65535;
+
+enum KernelId {
+    K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
+    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_COUNT
+};
+const char* const kKernelNames[K_COUNT] = {
+    "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
+    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth"};
+
+struct EvPair { hipEvent_t a, b; int kid; };
+
+struct Chunk { i64 p0, pc; size_t res_off; };
+
+struct Slot {
+    bool busy = false;
+    double* d_res = nullptr; double* h_res = nullptr; size_t res_cap = 0;   // doubles
+    i64* d_off = nullptr; i64* h_off = nullptr; size_t off_cap = 0;          // entries
+    mcr_summary out{};
+    i64 P = 0, M = 0; int nq = 0; int C = 0;
+    bool trivial_nan = false;  // M == 0: no kernels ran
+    i64 qlo[MCR_MAX_QUANTILES];
+    std::vector<Chunk> chunks;
+};
+
+char g_init_err[512] = "";
+
+}  // namespace
+
+struct mcr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = "";
+    size_t ws_limit = 0;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    void* stage = nullptr; size_t stage_bytes = 0;  // device copy of host tensors (mcr_summarize)
+    Slot slots[MCR_MAX_INFLIGHT];
+    int n_inflight = 0, next_slot = 0;
+    std::vector<int> order;  // busy slots in enqueue order
+    bool prof = false;
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> free_ev;
+    int64_t k_launches[K_COUNT] = {0};
+    double k_ms[K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(mcr_ctx* ctx, int code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : g_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MCR_ENOMEM : MCR_EHIP, "%s failed: %s", \
+                        #call, hipGetErrorString(e_));                                            \
+    } while (0)
+
+void prof_begin(mcr_ctx* ctx, int kid)
+{
+    if (!ctx->prof) return;
+    EvPair pr{nullptr, nullptr, kid};
+    for (hipEvent_t* e : {&pr.a, &pr.b}) {
+        if (!ctx->free_ev.empty()) { *e = ctx->free_ev.back(); ctx->free_ev.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) *e = nullptr;
+    }
+    if (pr.a && pr.b) { hipEventRecord(pr.a, ctx->stream); ctx->pending.push_back(pr); }
+}
+void prof_end(mcr_ctx* ctx)
+{
+    if (!ctx->prof || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().b, ctx->stream);
+}
+// Stream must be idle (synchronised) when this is called.
+void prof_resolve(mcr_ctx* ctx)
+{
+    for (EvPair& pr : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+            ctx->k_ms[pr.kid] += ms;
+            ctx->k_launches[pr.kid] += 1;
+        }
+        ctx->free_ev.push_back(pr.a);
+        ctx->free_ev.push_back(pr.b);
+    }
+    ctx->pending.clear();
+}
+
+#define LAUNCH(ctx, kid, kern, grid, block, smem, ...)                                         \
+    do {                                                                                       \
+        prof_begin(ctx, kid);                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, smem, (ctx)->stream, __VA_ARGS__);               \
+        prof_end(ctx);                                                                         \
+        hipError_t le_ = hipGetLastError();                                                    \
+        if (le_ != hipSuccess)                                                                 \
+            return fail(ctx, MCR_EHIP, "launch %s failed: %s", kKernelNames[kid],             \
+                        hipGetErrorString(le_));                                               \
+    } while (0)
+
+int ensure_ws(mcr_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return MCR_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) { hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    const size_t want = bytes + (bytes >> 3);  // a little slack so near-equal shapes do not realloc
+    hipError_t e = hipMalloc(&ctx->ws, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(&ctx->ws, bytes);
+        if (e != hipSuccess) return fail(ctx, MCR_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes,
+                                         hipGetErrorString(e));
+        ctx->ws_bytes = bytes;
+    } else {
+        ctx->ws_bytes = want;
+    }
+    return MCR_OK;
+}
+
+int ensure_slot(mcr_ctx* ctx, Slot& s, size_t res_doubles, size_t off_entries)
+{
+    if (res_doubles > s.res_cap) {
+        if (s.d_res) hipFree(s.d_res);
+        if (s.h_res) hipHostFree(s.h_res);
+        s.d_res = nullptr; s.h_res = nullptr; s.res_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&s.d_res, res_doubles * sizeof(double)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s.h_res, res_doubles * sizeof(double), hipHostMallocDefault));
+        s.res_cap = res_doubles;
+    }
+    if (off_entries > s.off_cap) {
+        if (s.d_off) hipFree(s.d_off);
+        if (s.h_off) hipHostFree(s.h_off);
+        s.d_off = nullptr; s.h_off = nullptr; s.off_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&s.d_off, off_entries * sizeof(i64)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s.h_off, off_entries * sizeof(i64), hipHostMallocDefault));
+        s.off_cap = off_entries;
+    }
+    return MCR_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carve {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t n)
+    {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct WsPlan {
+    size_t per_param;  // bytes per parameter (upper bound incl. alignment slack handled separately)
+    i64 ntiles;
+};
+
+WsPlan plan_ws(i64 M, bool ingest, bool ranks)
+{
+    WsPlan w;
+    w.ntiles = (M + kTile - 1) / kTile;
+    w.per_param = (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
+                  (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8;
+    return w;
+}
+
+struct PipeIn {
+    const double* X;     // [pc][M] f64 contiguous (user tensor or ingest buffer)
+    i64 M, pc;
+    int C;
+    const i64* d_off;
+    i64 n, nh;
+    QArgs q;
+    double* d_res;       // chunk's result table, stride pc
+    // carved buffers
+    double *kA, *kB, *zb, *zt, *part, *rank_b, *rank_t;
+    u32 *iA, *iB;
+    i64* split;
+    i64 ntiles;
+};
+
+template <int NT, bool STAGE>
+int launch_diag(mcr_ctx* ctx, const PipeIn& a, size_t lds)
+{
+    if (lds > 48 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<NT, STAGE>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAUNCH(ctx, K_DIAG, (k_diag<NT, STAGE>), dim3((unsigned)a.pc, 2), dim3(NT), lds, a.zb, a.zt, a.M,
+           a.d_off, a.C, a.n, a.nh, a.d_res, a.pc);
+    return MCR_OK;
+}
+
+// The whole per-chunk pipeline on ctx->stream.  M >= 1, pc >= 1.
+int run_pipeline(mcr_ctx* ctx, PipeIn& a)
+{
+    const i64 M = a.M, pc = a.pc;
+    const unsigned py = (unsigned)pc;
+    // 1. tile sort (+ moment partials)
+    LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<kSortNT, kSortVT>), dim3((unsigned)a.ntiles, py), dim3(kSortNT),
+           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles);
+    // 2. merge passes
+    double *kin = a.kA, *kout = a.kB;
+    u32 *iin = a.iA, *iout = a.iB;
+    const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
+    for (i64 R = kTile; R < M; R *= 2) {
+        LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+               (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
+               (const i64*)nullptr);
+        std::swap(kin, kout);
+        std::swap(iin, iout);
+    }
+    // 3. order statistics
+    LAUNCH(ctx, K_ORDER_STATS, k_order_stats, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
+           (const double*)kin, M, pc, a.q, a.d_res, a.split);
+    // 4. bulk ranks -> z
+    LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kin,
+           (const u32*)iin, M, a.zb, a.rank_b);
+    // 5. fold: one merge of the two monotone halves around the median
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+           (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
+           (const i64*)a.split);
+    // 6. folded ranks -> z
+    LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kout,
+           (const u32*)iout, M, a.zt, a.rank_t);
+    // 7. R-hat + ESS
+    if (a.C >= 2) {
+        const size_t small256 = (size_t)(4 + 6 * a.C + 64 + 4 * 64 + 4) * 8;
+        const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
+        int rc;
+        if (a.n <= 2048) rc = launch_diag<256, true>(ctx, a, small256 + (size_t)a.n * 8);
+        else if ((size_t)a.n * 8 + small1024 <= 150 * 1024) rc = launch_diag<1024, true>(ctx, a, small1024 + (size_t)a.n * 8);
+        else rc = launch_diag<1024, false>(ctx, a, small1024);
+        if (rc) return rc;
+    }
+    // 8. finalize
+    LAUNCH(ctx, K_FINALIZE, k_finalize, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0, (const double*)a.part,
+           (int)a.ntiles, M, a.X, pc, a.C, a.d_res);
+    return MCR_OK;
+}
+
+int prep_quantiles(mcr_ctx* ctx, const double* qs, int nq, i64 M, QArgs& q, i64* qlo_out)
+{
+    if (nq < 0 || nq > MCR_MAX_QUANTILES) return fail(ctx, MCR_EINVAL, "n_q must be in [0, %d]; got %d", MCR_MAX_QUANTILES, nq);
+    if (nq > 0 && !qs) return fail(ctx, MCR_EINVAL, "quantiles is NULL");
+    q.nq = nq;
+    for (int k = 0; k < nq; ++k) {
+        if (!(qs[k] >= 0.0 && qs[k] <= 1.0)) return fail(ctx, MCR_EINVAL, "Quantiles must be in the range [0, 1]");
+        const double h = (double)(M - 1) * qs[k];   // numpy: virtual index (n-1)*q ; arrow: same
+        const double fl = std::floor(h);
+        i64 lo = (i64)fl;
+        if (lo < 0) lo = 0;
+        if (M > 0 && lo > M - 1) lo = M - 1;
+        q.lo[k] = lo;
+        q.g[k] = h - fl;
+        qlo_out[k] = lo;
+    }
+    return MCR_OK;
+}
+
+constexpr int res_fields(int nq) { return R_Q0 + nq; }
+
+template <typename T>
+int launch_ingest(mcr_ctx* ctx, const void* src, double* X, i64 C, i64 N, i64 pc, i64 sc, i64 sn, i64 sp, i64 p0)
+{
+    if (sp == 1 && sn != 1 && pc > 1) {
+        const i64 nb = (N + 63) / 64;
+        LAUNCH(ctx, K_INGEST, (k_ingest_transpose<T>), dim3((unsigned)(nb * C), (unsigned)((pc + 63) / 64)),
+               dim3(256), 0, (const T*)src, X, C, N, pc, sc, sn, sp, p0);
+    } else {
+        const i64 nb = (N + 255) / 256;
+        LAUNCH(ctx, K_INGEST, (k_ingest_rows<T>), dim3((unsigned)(nb * C), (unsigned)pc), dim3(256), 0,
+               (const T*)src, X, C, N, sc, sn, sp, p0);
+    }
+    return MCR_OK;
+}
+
+void fill_nan(const mcr_summary& o, i64 P, int nq)
+{
+    double* arrs[] = {o.mean, o.std, o.median, o.rhat, o.rhat_bulk, o.rhat_tail, o.ess_bulk, o.ess_tail};
+    for (double* a : arrs)
+        if (a) for (i64 p = 0; p < P; ++p) a[p] = NAN;
+    if (o.q) for (i64 i = 0; i < P * nq; ++i) o.q[i] = NAN;
+    if (o.lag_bulk) for (i64 p = 0; p < P; ++p) o.lag_bulk[p] = 0;
+    if (o.lag_tail) for (i64 p = 0; p < P; ++p) o.lag_tail[p] = 0;
+}
+
+// Copies slot results (already on the host) into the caller's arrays.  Returns MCR_ENONFINITE
+// if any parameter saw NaN/Inf draws.
+int unpack_slot(mcr_ctx* ctx, Slot& s)
+{
+    const mcr_summary& o = s.out;
+    if (o.q_lo) for (int k = 0; k < s.nq; ++k) o.q_lo[k] = s.qlo[k];
+    if (s.trivial_nan) { fill_nan(o, s.P, s.nq); return MCR_OK; }
+    double nbad = 0.0;
+    for (const Chunk& ch : s.chunks) {
+        const double* r = s.h_res + ch.res_off;
+        const i64 pc = ch.pc;
+        auto cp = [&](double* dst, int field) {
+            if (dst) memcpy(dst + ch.p0, r + (size_t)field * pc, sizeof(double) * (size_t)pc);
+        };
+        cp(o.mean, R_MEAN); cp(o.std, R_STD); cp(o.median, R_MEDIAN); cp(o.rhat, R_RHAT);
+        cp(o.rhat_bulk, R_RHAT_BULK); cp(o.rhat_tail, R_RHAT_TAIL); cp(o.ess_bulk, R_ESS_BULK);
+        cp(o.ess_tail, R_ESS_TAIL);
+        for (i64 p = 0; p < pc; ++p) {
+            if (o.lag_bulk) o.lag_bulk[ch.p0 + p] = (int64_t)r[(size_t)R_LAG_BULK * pc + p];
+            if (o.lag_tail) o.lag_tail[ch.p0 + p] = (int64_t)r[(size_t)R_LAG_TAIL * pc + p];
+            nbad += r[(size_t)R_BAD * pc + p];
+            if (o.q) for (int k = 0; k < s.nq; ++k) o.q[(ch.p0 + p) * s.nq + k] = r[(size_t)(R_Q0 + k) * pc + p];
+        }
+    }
+    if (nbad > 0.0) return fail(ctx, MCR_ENONFINITE, "draws contain %.0f non-finite value(s)", nbad);
+    return MCR_OK;
+}
+
+int check_common(mcr_ctx* ctx, const void* draws, int dtype, i64 C, i64 N, i64 P, int min_chains,
+                 const mcr_summary* out)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (!out) return fail(ctx, MCR_EINVAL, "out is NULL");
+    if (dtype != MCR_F64 && dtype != MCR_F32) return fail(ctx, MCR_EINVAL, "unsupported dtype %d", dtype);
+    if (C < 0 || N < 0 || P < 0) return fail(ctx, MCR_EINVAL, "negative dimension (C=%lld N=%lld P=%lld)", C, N, P);
+    if (min_chains < 1) return fail(ctx, MCR_EMINCHAINS_ARG, "min_chains must be >= 1; got %d", min_chains);
+    if (C < min_chains)
+        return fail(ctx, MCR_EMINCHAINS, "diagnostics require at least %d chains; got %lld chain(s)", min_chains, C);
+    if (C > kMaxChains) return fail(ctx, MCR_EINVAL, "at most %d chains are supported; got %lld", kMaxChains, C);
+    if (C * N >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "C*N must be < 2^32");
+    if (!draws && C * N * P > 0) return fail(ctx, MCR_EINVAL, "draws is NULL");
+    return MCR_OK;
+}
+
+int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i64 P, i64 sc, i64 sn, i64 sp,
+                 int min_chains, const double* quantiles, int nq, const mcr_summary* out)
+{
+    int rc = check_common(ctx, draws_dev, dtype, C, N, P, min_chains, out);
+    if (rc) return rc;
+    if (ctx->n_inflight >= MCR_MAX_INFLIGHT) return fail(ctx, MCR_EINVAL, "more than %d summaries in flight", MCR_MAX_INFLIGHT);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 M = C * N;
+    int si = -1;
+    for (int k = 0; k < MCR_MAX_INFLIGHT; ++k) {
+        const int c = (ctx->next_slot + k) % MCR_MAX_INFLIGHT;
+        if (!ctx->slots[c].busy) { si = c; break; }
+    }
+    Slot& s = ctx->slots[si];
+    QArgs q;
+    rc = prep_quantiles(ctx, quantiles, nq, M, q, s.qlo);
+    if (rc) return rc;
+    s.out = *out; s.P = P; s.M = M; s.nq = nq; s.C = (int)C;
+    s.chunks.clear();
+    s.trivial_nan = (M == 0 || P == 0);
+    if (!s.trivial_nan) {
+        const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
+        const WsPlan wp = plan_ws(M, ingest, false);
+        const size_t slack = 16 * 256;
+        if (wp.per_param + slack > ctx->ws_limit)
+            return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
+        i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
+        if (pcmax > P) pcmax = P;
+        if (pcmax > kMaxGridY) pcmax = kMaxGridY;
+        rc = ensure_ws(ctx, (size_t)pcmax * wp.per_param + slack);
+        if (rc) return rc;
+        const int R = res_fields(nq);
+        rc = ensure_slot(ctx, s, (size_t)R * (size_t)P, (size_t)C + 1);
+        if (rc) return rc;
+        for (i64 c = 0; c <= C; ++c) s.h_off[c] = c * N;
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+        for (i64 p0 = 0; p0 < P; p0 += pcmax) {
+            const i64 pc = (P - p0 < pcmax) ? P - p0 : pcmax;
+            Carve cv{reinterpret_cast<char*>(ctx->ws)};
+            PipeIn a{};
+            a.M = M; a.pc = pc; a.C = (int)C; a.d_off = s.d_off; a.n = N; a.nh = (N >= 2) ? N / 2 : 0; a.q = q;
+            a.ntiles = wp.ntiles;
+            a.kA = cv.take<double>((size_t)pc * M); a.kB = cv.take<double>((size_t)pc * M);
+            a.iA = cv.take<u32>((size_t)pc * M);    a.iB = cv.take<u32>((size_t)pc * M);
+            a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
+            a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
+            a.split = cv.take<i64>((size_t)pc);
+            a.rank_b = a.rank_t = nullptr;
+            if (ingest) {
+                double* X = cv.take<double>((size_t)pc * M);
+                rc = (dtype == MCR_F64) ? launch_ingest<double>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0)
+                                        : launch_ingest<float>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0);
+                if (rc) return rc;
+                a.X = X;
+            } else {
+                a.X = reinterpret_cast<const double*>(draws_dev) + p0 * M;
+            }
+            const size_t res_off = (size_t)R * (size_t)p0;
+            a.d_res = s.d_res + res_off;
+            rc = run_pipeline(ctx, a);
+            if (rc) return rc;
+            s.chunks.push_back(Chunk{p0, pc, res_off});
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(s.h_res, s.d_res, sizeof(double) * (size_t)R * (size_t)P, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    }
+    s.busy = true;
+    ctx->order.push_back(si);
+    ctx->n_inflight++;
+    ctx->next_slot = (si + 1) % MCR_MAX_INFLIGHT;
+    return MCR_OK;
+}
+
+int wait_impl(mcr_ctx* ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    int rc = MCR_OK;
+    for (int si : ctx->order) {
+        Slot& s = ctx->slots[si];
+        const int r = unpack_slot(ctx, s);
+        if (r && !rc) rc = r;
+        s.busy = false;
+    }
+    ctx->order.clear();
+    ctx->n_inflight = 0;
+    return rc;
+}
+
+// Drops any enqueued-but-unwaited work after an error so the ctx stays usable.
+void abort_inflight(mcr_ctx* ctx)
+{
+    hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
+    for (int si : ctx->order) ctx->slots[si].busy = false;
+    ctx->order.clear();
+    ctx->n_inflight = 0;
+}
+
+int ensure_stage(mcr_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return MCR_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stage) { hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return MCR_OK;
+}
+
+// Extent (in elements) touched by a strided tensor, or -1 if strides are negative.
+i64 tensor_extent(i64 C, i64 N, i64 P, i64 sc, i64 sn, i64 sp)
+{
+    if (C == 0 || N == 0 || P == 0) return 0;
+    if (sc < 0 || sn < 0 || sp < 0) return -1;
+    return (C - 1) * sc + (N - 1) * sn + (P - 1) * sp + 1;
+}
+
+template <typename T>
+int moments_impl(mcr_ctx* ctx, const T* src, i64 C, i64 N, i64 P, i64 sc, i64 sn, i64 sp, double* d_mean,
+                 double* d_std, double* part, int S, bool rows)
+{
+    const i64 M = C * N;
+    if (rows) {
+        LAUNCH(ctx, K_MOMENTS, (k_moments_rows<T>), dim3((unsigned)S, (unsigned)P), dim3(256), 0, src, M, sp, part, S);
+    } else {
+        LAUNCH(ctx, K_MOMENTS, (k_moments_cols<T>), dim3((unsigned)((P + 63) / 64), (unsigned)S), dim3(256), 0, src,
+               C, N, P, sc, sn, sp, part, S);
+    }
+    LAUNCH(ctx, K_MOMENTS_FINAL, (k_moments_final<T>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+           (const double*)part, S, M, src, sp, P, d_mean, d_std, (double*)nullptr);
+    return MCR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int mcr_version(void) { return MCR_VERSION; }
+
+int mcr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mcr_last_error(const mcr_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
+
+int mcr_init(int device, mcr_ctx** out)
+{
+    if (!out) return fail(nullptr, MCR_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, MCR_ENODEVICE, "no HIP device available (%s); libmcmcref_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(nullptr, MCR_ENODEVICE, "device %d out of range [0, %d)", device, n);
+    mcr_ctx* ctx = new (std::nothrow) mcr_ctx();
+    if (!ctx) return fail(nullptr, MCR_ENOMEM, "out of host memory");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MCR_EHIP, "device %d init failed: %s", device, hipGetErrorString(e));
+    }
+    size_t mb = 8192;
+    if (const char* env = getenv("MCR_WORKSPACE_MB")) { const long v = atol(env); if (v > 0) mb = (size_t)v; }
+    ctx->ws_limit = mb << 20;
+    *out = ctx;
+    return MCR_OK;
+}
+
+void mcr_free(mcr_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
+    for (hipEvent_t e : ctx->free_ev) hipEventDestroy(e);
+    for (Slot& s : ctx->slots) {
+        if (s.d_res) hipFree(s.d_res);
+        if (s.h_res) hipHostFree(s.h_res);
+        if (s.d_off) hipFree(s.d_off);
+        if (s.h_off) hipHostFree(s.h_off);
+    }
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (bytes < (1u << 20)) return fail(ctx, MCR_EINVAL, "workspace limit must be at least 1 MiB");
+    ctx->ws_limit = bytes;
+    return MCR_OK;
+}
+
+int mcr_dev_alloc(mcr_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return fail(ctx, MCR_EINVAL, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return MCR_OK;
+}
+int mcr_dev_free(mcr_ctx* ctx, void* dptr)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dptr) HIP_TRY(ctx, hipFree(dptr));
+    return MCR_OK;
+}
+int mcr_memcpy_h2d(mcr_ctx* ctx, void* dptr, const void* hptr, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCR_OK;
+}
+int mcr_memcpy_d2h(mcr_ctx* ctx, void* hptr, const void* dptr, size_t bytes)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCR_OK;
+}
+int mcr_sync(mcr_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCR_OK;
+}
+
+int mcr_summarize_enqueue(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P,
+                          int64_t sc, int64_t sn, int64_t sp, int min_chains, const double* quantiles, int n_q,
+                          mcr_summary* out)
+{
+    const int rc = enqueue_impl(ctx, draws_dev, dtype, C, N, P, sc, sn, sp, min_chains, quantiles, n_q, out);
+    if (rc && ctx && rc != MCR_EMINCHAINS && rc != MCR_EMINCHAINS_ARG && rc != MCR_EINVAL) {
+        char keep[512];
+        memcpy(keep, ctx->err, sizeof keep);
+        abort_inflight(ctx);
+        memcpy(ctx->err, keep, sizeof keep);
+    }
+    return rc;
+}
+
+int mcr_summarize_wait(mcr_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    return wait_impl(ctx);
+}
+
+int mcr_summarize_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t sc,
+                      int64_t sn, int64_t sp, int min_chains, const double* quantiles, int n_q, mcr_summary* out)
+{
+    int rc = mcr_summarize_enqueue(ctx, draws_dev, dtype, C, N, P, sc, sn, sp, min_chains, quantiles, n_q, out);
+    if (rc) return rc;
+    return wait_impl(ctx);
+}
+
+int mcr_summarize(mcr_ctx* ctx, const void* draws, int dtype, int64_t C, int64_t N, int64_t P, int64_t sc,
+                  int64_t sn, int64_t sp, int min_chains, const double* quantiles, int n_q, mcr_summary* out)
+{
+    int rc = check_common(ctx, draws, dtype, C, N, P, min_chains, out);
+    if (rc) return rc;
+    const i64 ext = tensor_extent(C, N, P, sc, sn, sp);
+    if (ext < 0) return fail(ctx, MCR_EINVAL, "negative strides are not supported");
+    const size_t es = dtype == MCR_F64 ? 8 : 4;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ext > 0) {
+        rc = ensure_stage(ctx, (size_t)ext * es);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->stage, draws, (size_t)ext * es, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return mcr_summarize_dev(ctx, ctx->stage, dtype, C, N, P, sc, sn, sp, min_chains, quantiles, n_q, out);
+}
+
+int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain_off, int C, int min_chains,
+                        mcr_summary* out, double* z_bulk, double* z_tail, double* rank_bulk, double* rank_tail)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (!out) return fail(ctx, MCR_EINVAL, "out is NULL");
+    if (C < 0) return fail(ctx, MCR_EINVAL, "negative chain count");
+    if (min_chains < 1) return fail(ctx, MCR_EMINCHAINS_ARG, "min_chains must be >= 1; got %d", min_chains);
+    if (C < min_chains) return fail(ctx, MCR_EMINCHAINS, "diagnostics require at least %d chains; got %d chain(s)", min_chains, C);
+    if (C > kMaxChains) return fail(ctx, MCR_EINVAL, "at most %d chains are supported; got %d", kMaxChains, C);
+    if (C > 0 && !chain_off) return fail(ctx, MCR_EINVAL, "chain_off is NULL");
+    if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_diagnose_chains with summaries in flight");
+    const i64 M = C > 0 ? chain_off[C] : 0;
+    if (M < 0 || M >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "pooled length out of range");
+    i64 n = 0, nh = 0;
+    bool have_h = false;
+    for (int c = 0; c < C; ++c) {
+        const i64 len = chain_off[c + 1] - chain_off[c];
+        if (len < 0) return fail(ctx, MCR_EINVAL, "chain_off must be non-decreasing");
+        if (c == 0 || len < n) n = len;
+        if (len >= 2) { if (!have_h || len / 2 < nh) nh = len / 2; have_h = true; }
+    }
+    if (M > 0 && !pooled) return fail(ctx, MCR_EINVAL, "pooled is NULL");
+    Slot& s = ctx->slots[0];
+    s.out = *out; s.P = 1; s.M = M; s.nq = 0; s.C = C; s.chunks.clear();
+    s.trivial_nan = (M == 0);
+    if (s.trivial_nan) { s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1; return wait_impl(ctx); }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool want_rank = rank_bulk || rank_tail;
+    const WsPlan wp = plan_ws(M, true, want_rank);
+    const size_t slack = 16 * 256;
+    if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
+    int rc = ensure_ws(ctx, wp.per_param + slack);
+    if (rc) return rc;
+    const int R = res_fields(0);
+    rc = ensure_slot(ctx, s, (size_t)R, (size_t)C + 1);
+    if (rc) return rc;
+    memcpy(s.h_off, chain_off, sizeof(i64) * (size_t)(C + 1));
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    PipeIn a{};
+    a.M = M; a.pc = 1; a.C = C; a.d_off = s.d_off; a.n = n; a.nh = nh; a.q.nq = 0; a.ntiles = wp.ntiles;
+    a.kA = cv.take<double>((size_t)M); a.kB = cv.take<double>((size_t)M);
+    a.iA = cv.take<u32>((size_t)M);    a.iB = cv.take<u32>((size_t)M);
+    a.zb = cv.take<double>((size_t)M); a.zt = cv.take<double>((size_t)M);
+    a.part = cv.take<double>((size_t)wp.ntiles * 4);
+    a.split = cv.take<i64>(1);
+    double* X = cv.take<double>((size_t)M);
+    a.rank_b = want_rank ? cv.take<double>((size_t)M) : nullptr;
+    a.rank_t = want_rank ? cv.take<double>((size_t)M) : nullptr;
+    HIP_TRY(ctx, hipMemcpyAsync(X, pooled, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, ctx->stream));
+    a.X = X;
+    a.d_res = s.d_res;
+    rc = run_pipeline(ctx, a);
+    if (rc) { abort_inflight(ctx); return rc; }
+    s.chunks.push_back(Chunk{0, 1, 0});
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_res, s.d_res, sizeof(double) * (size_t)R, hipMemcpyDeviceToHost, ctx->stream));
+    auto back = [&](double* dst, const double* srcp) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, srcp, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    };
+    HIP_TRY(ctx, back(z_bulk, a.zb));
+    HIP_TRY(ctx, back(z_tail, a.zt));
+    HIP_TRY(ctx, back(rank_bulk, a.rank_b));
+    HIP_TRY(ctx, back(rank_tail, a.rank_t));
+    s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1;
+    return wait_impl(ctx);
+}
+
+int mcr_moments_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t sc,
+                    int64_t sn, int64_t sp, double* mean, double* std)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (dtype != MCR_F64 && dtype != MCR_F32) return fail(ctx, MCR_EINVAL, "unsupported dtype %d", dtype);
+    if (C < 0 || N < 0 || P < 0 || !mean || !std) return fail(ctx, MCR_EINVAL, "bad argument");
+    const i64 M = C * N;
+    if (P == 0) return MCR_OK;
+    if (M == 0) { for (i64 p = 0; p < P; ++p) mean[p] = std[p] = NAN; return MCR_OK; }
+    if (!draws_dev) return fail(ctx, MCR_EINVAL, "draws is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool rows = (N <= 1 || sn == 1) && (C <= 1 || sc == N);
+    if (rows && P > kMaxGridY) return fail(ctx, MCR_EINVAL, "P > %d not supported by mcr_moments_dev rows path", kMaxGridY);
+    int S;
+    if (rows) {
+        const i64 vec = dtype == MCR_F64 ? 2 : 4;
+        i64 smax = (M + 256 * vec * 4 - 1) / (256 * vec * 4);   // >= one unrolled sweep per block
+        i64 want = (4096 + P - 1) / P;
+        S = (int)(want < smax ? want : smax);
+        if (S < 1) S = 1;
+    } else {
+        i64 want = (2048 + (P + 63) / 64 - 1) / ((P + 63) / 64);
+        i64 smax = (M + 63) / 64;
+        S = (int)(want < smax ? want : smax);
+        if (S < 1) S = 1;
+        if (S > kMaxGridY) S = kMaxGridY;
+    }
+    const size_t need = align_up((size_t)P * S * 32, 256) + align_up((size_t)P * 8, 256) * 2 + 1024;
+    int rc = ensure_ws(ctx, need);
+    if (rc) return rc;
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    double* part = cv.take<double>((size_t)P * S * 4);
+    double* d_mean = cv.take<double>((size_t)P);
+    double* d_std = cv.take<double>((size_t)P);
+    rc = dtype == MCR_F64 ? moments_impl<double>(ctx, (const double*)draws_dev, C, N, P, sc, sn, sp, d_mean, d_std, part, S, rows)
+                          : moments_impl<float>(ctx, (const float*)draws_dev, C, N, P, sc, sn, sp, d_mean, d_std, part, S, rows);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(std, d_std, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
+int mcr_basic_stats(mcr_ctx* ctx, const void* values, int dtype, int64_t n, double* mean, double* std)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (!mean || !std || n < 0) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (dtype != MCR_F64 && dtype != MCR_F32) return fail(ctx, MCR_EINVAL, "unsupported dtype %d", dtype);
+    if (n == 0) { *mean = NAN; *std = NAN; return MCR_OK; }   /* compare.py:60-61 */
+    if (!values) return fail(ctx, MCR_EINVAL, "values is NULL");
+    const size_t es = dtype == MCR_F64 ? 8 : 4;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_stage(ctx, (size_t)n * es);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage, values, (size_t)n * es, hipMemcpyHostToDevice, ctx->stream));
+    return mcr_moments_dev(ctx, ctx->stage, dtype, 1, n, 1, n, 1, n, mean, std);
+}
+
+int mcr_compare(mcr_ctx* ctx, const double* ref, const double* actual, int64_t n, double tol, double* rel_error,
+                uint8_t* passed)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!ref || !actual || !rel_error || !passed))) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (n == 0) return MCR_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = align_up((size_t)n * 8, 256) * 3 + align_up((size_t)n, 256) + 1024;
+    int rc = ensure_ws(ctx, need);
+    if (rc) return rc;
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    double* d_ref = cv.take<double>((size_t)n);
+    double* d_act = cv.take<double>((size_t)n);
+    double* d_rel = cv.take<double>((size_t)n);
+    unsigned char* d_ok = cv.take<unsigned char>((size_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_act, actual, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, K_COMPARE, k_compare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const double*)d_ref,
+           (const double*)d_act, (i64)n, tol, d_rel, d_ok);
+    HIP_TRY(ctx, hipMemcpyAsync(rel_error, d_rel, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(passed, d_ok, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
+int mcr_profile_enable(mcr_ctx* ctx, int on)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    ctx->prof = on != 0;
+    return MCR_OK;
+}
+int mcr_profile_reset(mcr_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    for (int k = 0; k < K_COUNT; ++k) { ctx->k_launches[k] = 0; ctx->k_ms[k] = 0.0; }
+    return MCR_OK;
+}
+int mcr_profile_get(mcr_ctx* ctx, mcr_kernel_time* out, int max, int* n)
+{
+    if (!ctx || !n) return fail(ctx, MCR_EINVAL, "NULL argument");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    int cnt = 0;
+    for (int k = 0; k < K_COUNT; ++k) {
+        if (!ctx->k_launches[k]) continue;
+        if (out && cnt < max) {
+            memset(&out[cnt], 0, sizeof(mcr_kernel_time));
+            strncpy(out[cnt].name, kKernelNames[k], sizeof(out[cnt].name) - 1);
+            out[cnt].launches = ctx->k_launches[k];
+            out[cnt].total_ms = ctx->k_ms[k];
+        }
+        ++cnt;
+    }
+    *n = cnt;
+    return MCR_OK;
+}
+
+int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, uint64_t seed)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (dtype != MCR_F64 && dtype != MCR_F32) return fail(ctx, MCR_EINVAL, "unsupported dtype %d", dtype);
+    const i64 total = C * N * P;
+    if (total <= 0) return MCR_OK;
+    if (!draws_dev) return fail(ctx, MCR_EINVAL, "draws is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    i64 blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (dtype == MCR_F64) {
+        LAUNCH(ctx, K_FILL, (k_fill_synth<double>), dim3((unsigned)blocks), dim3(256), 0, (double*)draws_dev, total,
+               (i64)(C * N), (u64)seed);
+    } else {
+        LAUNCH(ctx, K_FILL, (k_fill_synth<float>), dim3((unsigned)blocks), dim3(256), 0, (float*)draws_dev, total,
+               (i64)(C * N), (u64)seed);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// mcr_device.hpp -- device-side building blocks (gfx950 / CDNA4, wave64).
+//
+// Everything here is written for 64-lane wavefronts and fp64 VALU; nothing is shaped for MFMA
+// (the path is sort / scan / reduce work: HBM- and LDS-bound).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcr {
+
+using i64 = long long;
+using u32 = unsigned int;
+using u64 = unsigned long long;
+
+constexpr int kWave = 64;
+
+// ---- reductions ----------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Deterministic block sum (fixed association order): wave shuffle tree, then waves in index order.
+// `red` is LDS scratch of NT/64 doubles.  Every thread gets the result.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+    v = wave_sum(v);
+    __syncthreads();  // `red` may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / kWave; ++w) r += red[w];
+    return r;
+}
+
+// ---- AS241 (Wichura 1988) PPND16: z = Phi^-1(p) -----------------------------------------------
+// Same evaluation order as statistics.NormalDist.inv_cdf, which the reference calls at
+// src/mcmc_ref/diagnostics.py:131.  Contraction is disabled so the central branch
+// (|p-0.5| <= 0.425, pure +,*,/) is bit-identical to the CPU evaluation.
+__device__ __noinline__ double inv_cdf(double p)
+{
+#pragma clang fp contract(off)
+    double q = p - 0.5, r, num, den, x;
+    if (fabs(q) <= 0.425) {
+        r = 0.180625 - q * q;
+        num = (((((((2.5090809287301226727e+3 * r + 3.3430575583588128105e+4) * r +
+                    6.7265770927008700853e+4) * r + 4.5921953931549871457e+4) * r +
+                  1.3731693765509461125e+4) * r + 1.9715909503065514427e+3) * r +
+                1.3314166789178437745e+2) * r + 3.3871328727963666080e+0) * q;
+        den = (((((((5.2264952788528545610e+3 * r + 2.8729085735721942674e+4) * r +
+                    3.9307895800092710610e+4) * r + 2.1213794301586595867e+4) * r +
+                  5.3941960214247511077e+3) * r + 6.8718700749205790830e+2) * r +
+                4.2313330701600911252e+1) * r + 1.0);
+        return num / den;
+    }
+    r = (q <= 0.0) ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    if (r <= 5.0) {
+        r = r - 1.6;
+        num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r +
+                    2.41780725177450611770e-1) * r + 1.27045825245236838258e+0) * r +
+                  3.64784832476320460504e+0) * r + 5.76949722146069140550e+0) * r +
+                4.63033784615654529590e+0) * r + 1.42343711074968357734e+0);
+        den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r +
+                    1.51986665636164571966e-2) * r + 1.48103976427480074590e-1) * r +
+                  6.89767334985100004550e-1) * r + 1.67638483018380384940e+0) * r +
+                2.05319162663775882187e+0) * r + 1.0);
+    } else {
+        r = r - 5.0;
+        num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r +
+                    1.24266094738807843860e-3) * r + 2.65321895265761230930e-2) * r +
+                  2.96560571828504891230e-1) * r + 1.78482653991729133580e+0) * r +
+                5.46378491116411436990e+0) * r + 6.65790464350110377720e+0);
+        den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r +
+                    1.84631831751005468180e-5) * r + 7.86869131145613259100e-4) * r +
+                  1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
+                5.99832206555887937690e-1) * r + 1.0);
+    }
+    x = num / den;
+    return (q < 0.0) ? -x : x;
+}
+
+// ---- merge path --------------------------------------------------------------------------------
+// Split point of diagonal `diag` for two ascending runs given by accessors a(i), b(j):
+// returns ai (and bi = diag - ai) such that merging takes a[0..ai) and b[0..bi) first.  Ties
+// take from `a` first.  Comparisons are on doubles, so -0.0 == +0.0 (as Python compares them).
+template <class FA, class FB>
+__device__ __forceinline__ i64 merge_path(FA a, i64 na, FB b, i64 nb, i64 diag)
+{
+    i64 lo = diag > nb ? diag - nb : 0;
+    i64 hi = diag < na ? diag : na;
+    while (lo < hi) {
+        i64 mid = (lo + hi) >> 1;
+        double ak = a(mid), bk = b(diag - 1 - mid);
+        if (!(bk < ak)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// LDS index padding: one pad slot per 16 elements, so that "thread t owns elements
+// [16t, 16t+16)" accesses (stride 17 doubles across lanes) are bank-conflict free.
+__device__ __forceinline__ int pos16(int e) { return e + (e >> 4); }
+
+// ---- counter-based generator (bench / stress tensor) ------------------------------------------
+__host__ __device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace mcr

@@ -1,0 +1,745 @@
+// mcr_kernels.hpp -- the HIP kernels of the statistics hot path (gfx950, wave64, fp64 VALU).
+//
+// Per model (C chains x N draws, M = C*N pooled draws per parameter, P parameters) the pipeline is
+//
+//   k_ingest_*      (only if the tensor is not already f64 [P][C][N])  strided/f32 -> X[P][M] f64
+//   k_tile_sort     X -> sorted tiles of (key f64, idx u32) + per-tile shifted moment partials
+//   k_merge<false>  log2(#tiles) merge-path passes -> pooled ascending order per parameter
+//   k_order_stats   quantiles, median, fold split point                         (a2/a3/a8)
+//   k_rank_z        tie-averaged ranks -> z = Phi^-1((r-0.5)/M), scattered to time order (a7)
+//   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort) (a8)
+//   k_rank_z        same for the folded values
+//   k_diag          split R-hat + ESS (first-negative-rho truncation) for bulk and folded z (a9-a13)
+//   k_finalize      mean/std from partials, rhat = pymax(bulk, tail), packs the result table
+//
+// (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
+#pragma once
+#include "mcr_device.hpp"
+
+namespace mcr {
+
+// result table: SoA, res[field * P + p]
+enum ResField {
+    R_MEAN = 0, R_STD, R_MEDIAN, R_RHAT, R_RHAT_BULK, R_RHAT_TAIL, R_ESS_BULK, R_ESS_TAIL,
+    R_LAG_BULK, R_LAG_TAIL, R_BAD, R_Q0  // R_Q0 .. R_Q0 + nq - 1
+};
+
+struct QArgs {
+    int nq;
+    i64 lo[32];
+    double g[32];
+};
+
+// ------------------------------------------------------------------------------------------------
+// Ingest: arbitrary element strides / f32 -> X[p][c*N + t] f64.
+// rows variant: lanes run along t (coalesced when stride_n == 1).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ingest_rows(const T* __restrict__ src, double* __restrict__ X,
+                                                     i64 C, i64 N, i64 sc, i64 sn, i64 sp, i64 p0)
+{
+    const i64 nb = (N + 255) / 256;
+    const i64 c = blockIdx.x / nb, t = (blockIdx.x % nb) * 256 + threadIdx.x;
+    const i64 p = blockIdx.y;
+    if (t < N) X[p * (C * N) + c * N + t] = (double)src[c * sc + t * sn + (p0 + p) * sp];
+}
+
+// transpose variant: lanes run along p on the read side (coalesced when stride_p == 1, i.e. the
+// [C][N][P] layout of Draws.to_numpy, src/mcmc_ref/draws.py:28-29), along t on the write side.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ingest_transpose(const T* __restrict__ src,
+                                                          double* __restrict__ X, i64 C, i64 N, i64 P,
+                                                          i64 sc, i64 sn, i64 sp, i64 p0)
+{
+    __shared__ double tile[64][65];
+    const i64 nb = (N + 63) / 64;
+    const i64 c = blockIdx.x / nb, t0 = (blockIdx.x % nb) * 64;
+    const i64 pl0 = (i64)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const i64 t = t0 + r, p = pl0 + tx;
+        tile[r][tx] = (t < N && p < P) ? (double)src[c * sc + t * sn + (p0 + p) * sp] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) {
+        const i64 t = t0 + tx, p = pl0 + q;
+        if (t < N && p < P) X[p * (C * N) + c * N + t] = tile[tx][q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming moments (a2/a3/a4): one HBM pass, shifted sums S1 = sum(x-K), S2 = sum((x-K)^2) with
+// K = the parameter's first draw, so mean = K + S1/M, var = (S2 - S1^2/M)/M without catastrophic
+// cancellation.  Mirrors np.mean / np.std(ddof=0) (src/mcmc_ref/backends_numpy.py:41-42),
+// pc.mean / pc.stddev (backends_arrow.py:38-39) and compute_basic_stats (compare.py:58-64).
+// part[(p*S + s)*4 + {0,1,2}] = S1, S2, non-finite count.
+// rows variant: grid (S, P); the block streams a contiguous slice of X[p][.] with 16-byte loads.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i64 M, i64 pstride,
+                                                      double* __restrict__ part, int S)
+{
+    __shared__ double red[4];
+    const i64 p = blockIdx.y;
+    const int s = blockIdx.x;
+    const T* x = X + p * pstride;
+    const double K = (double)x[0];
+    constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+    i64 per = (M + S - 1) / S;
+    per = (per + V - 1) / V * V;
+    const i64 b = s * per, e = (b + per < M) ? b + per : M;
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    auto acc1 = [&](double v) {
+        const double d = v - K;
+        s1 += d; s2 = fma(d, d, s2);
+        bad += isfinite(v) ? 0.0 : 1.0;
+    };
+    i64 scalar_from = b;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && e > b) {
+        const i64 nvec = (e - b) / V;  // b is a multiple of V, so x + b stays 16-byte aligned
+        const float4* xv = reinterpret_cast<const float4*>(x + b);
+        i64 g = threadIdx.x;
+        for (; g + 3 * 256 < nvec; g += 4 * 256) {  // 4 independent 16-byte loads in flight per lane
+            float4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = xv[g + u * 256];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* v = reinterpret_cast<const T*>(&r[u]);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc1((double)v[j]);
+            }
+        }
+        for (; g < nvec; g += 256) {
+            const float4 r = xv[g];
+            const T* v = reinterpret_cast<const T*>(&r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc1((double)v[j]);
+        }
+        scalar_from = b + nvec * V;
+    }
+    for (i64 j = scalar_from + threadIdx.x; j < e; j += 256) acc1((double)x[j]);
+    s1 = block_sum<256>(s1, red);
+    s2 = block_sum<256>(s2, red);
+    bad = block_sum<256>(bad, red);
+    if (threadIdx.x == 0) {
+        double* o = part + (p * S + s) * 4;
+        o[0] = s1; o[1] = s2; o[2] = bad; o[3] = 0.0;
+    }
+}
+
+// strided variant ([C][N][P]-like tensors, stride_p == 1): lanes run along p, each thread owns one
+// parameter and walks a slice of the C*N rows.  grid (ceil(P/64), S), block (64, 4).
+template <typename T>
+__global__ __launch_bounds__(256) void k_moments_cols(const T* __restrict__ src, i64 C, i64 N, i64 P,
+                                                      i64 sc, i64 sn, i64 sp, double* __restrict__ part,
+                                                      int S)
+{
+    __shared__ double sh[3][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const i64 p = (i64)blockIdx.x * 64 + tx;
+    const int s = blockIdx.y;
+    const i64 M = C * N;
+    const i64 per = (M + S - 1) / S, b = s * per, e = (b + per < M) ? b + per : M;
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    if (p < P) {
+        const double K = (double)src[p * sp];
+        for (i64 r = b + ty; r < e; r += 4) {
+            const i64 c = r / N, t = r - c * N;
+            const double v = (double)src[c * sc + t * sn + p * sp], d = v - K;
+            s1 += d; s2 = fma(d, d, s2);
+            bad += isfinite(v) ? 0.0 : 1.0;
+        }
+    }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2; sh[2][ty][tx] = bad;
+    __syncthreads();
+    if (ty == 0 && p < P) {
+        double* o = part + (p * S + s) * 4;
+        o[0] = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
+        o[1] = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
+        o[2] = sh[2][0][tx] + sh[2][1][tx] + sh[2][2][tx] + sh[2][3][tx];
+        o[3] = 0.0;
+    }
+}
+
+// mean/std from S partials per parameter (fixed summation order).  first[p] = the shift K.
+// When res == nullptr writes mean[p], std[p] directly (mcr_moments_dev / mcr_basic_stats).
+template <typename T>
+__global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, const T* __restrict__ src,
+                                i64 kstride, i64 P, double* __restrict__ mean, double* __restrict__ stdv,
+                                double* __restrict__ bad)
+{
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double s1 = 0.0, s2 = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double* o = part + (p * S + s) * 4;
+        s1 += o[0]; s2 += o[1]; b += o[2];
+    }
+    const double K = (double)src[p * kstride];
+    const double m = (double)M;
+    const double mu = s1 / m;
+    double var = (s2 - s1 * mu) / m;
+    if (var < 0.0) var = 0.0;
+    mean[p] = K + mu;
+    stdv[p] = sqrt(var);
+    if (bad) bad[p] = b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile sort: one workgroup sorts T = NT*VT pooled draws of one parameter entirely in LDS
+// (thread-local odd-even network over VT registers, then log2(NT) merge-path levels), carrying the
+// pooled position as a u32 payload.  Spec: the `sorted(flat, key=...)` of
+// src/mcmc_ref/diagnostics.py:110 (stability is irrelevant: ties share one average rank).
+// Also emits the shifted moment partials of its tile (so the draws are read from HBM once).
+// Partial tiles are padded with +inf (draws are finite or the call fails with MCR_ENONFINITE).
+// ------------------------------------------------------------------------------------------------
+template <int VT>
+__device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
+{
+#pragma unroll
+    for (int round = 0; round < VT; ++round) {
+#pragma unroll
+        for (int i = (round & 1); i + 1 < VT; i += 2) {
+            const bool sw = k[i + 1] < k[i];
+            const double a = sw ? k[i + 1] : k[i], b = sw ? k[i] : k[i + 1];
+            const u32 ia = sw ? ix[i + 1] : ix[i], ib = sw ? ix[i] : ix[i + 1];
+            k[i] = a; k[i + 1] = b; ix[i] = ia; ix[i + 1] = ib;
+        }
+    }
+}
+
+// Serial merge of up to VT outputs from LDS runs A = skey[pos(a0 + .)] (na items) and
+// B = skey[pos(b0 + .)] (nb items), starting at (ai, bi).  src[i] = LDS slot the output came from.
+template <int VT>
+__device__ __forceinline__ void serial_merge(const double* skey, int a0, int na, int b0, int nb, int ai,
+                                             int bi, int nout, double (&k)[VT], int (&src)[VT])
+{
+    double ak = (ai < na) ? skey[pos16(a0 + ai)] : 0.0;
+    double bk = (bi < nb) ? skey[pos16(b0 + bi)] : 0.0;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        if (i < nout) {
+            const bool takeA = (bi >= nb) || (ai < na && !(bk < ak));
+            k[i] = takeA ? ak : bk;
+            src[i] = takeA ? a0 + ai : b0 + bi;
+            ai += takeA ? 1 : 0;
+            bi += takeA ? 0 : 1;
+            const int nxt = takeA ? a0 + ai : b0 + bi;
+            const bool ok = takeA ? (ai < na) : (bi < nb);
+            const double nv = ok ? skey[pos16(nxt)] : 0.0;
+            ak = takeA ? nv : ak;
+            bk = takeA ? bk : nv;
+        } else {
+            src[i] = 0;
+        }
+    }
+}
+
+template <int NT, int VT>
+__global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, i64 M,
+                                                  double* __restrict__ keys, u32* __restrict__ idx,
+                                                  double* __restrict__ part, int ntiles)
+{
+    constexpr int T = NT * VT;
+    constexpr int TP = T + T / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* skey = reinterpret_cast<double*>(smem);
+    u32* sidx = reinterpret_cast<u32*>(skey + TP);
+    double* red = reinterpret_cast<double*>(sidx + TP);  // TP*12 is a multiple of 8
+
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const i64 p = blockIdx.y;
+    const i64 base = (i64)tile * T;
+    const int count = (int)((M - base < (i64)T) ? M - base : (i64)T);
+    const double* src = X + p * M + base;
+    const double K = X[p * M];
+
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int e = i * NT + tid;
+        double v = INFINITY;
+        if (e < count) {
+            v = src[e];
+            const double d = v - K;
+            s1 += d; s2 = fma(d, d, s2);
+            bad += isfinite(v) ? 0.0 : 1.0;
+        }
+        skey[pos16(e)] = v;
+    }
+    __syncthreads();
+
+    double k[VT];
+    u32 ix[VT];
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int e = tid * VT + i;
+        k[i] = skey[pos16(e)];
+        ix[i] = (e < count) ? (u32)(base + e) : 0xFFFFFFFFu;
+    }
+    thread_sort<VT>(k, ix);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int e = tid * VT + i;
+        skey[pos16(e)] = k[i];
+        sidx[pos16(e)] = ix[i];
+    }
+    __syncthreads();
+
+    for (int coop = 2; coop <= NT; coop <<= 1) {
+        const int first = tid & ~(coop - 1);
+        const int run = VT * (coop >> 1);
+        const int a0 = first * VT, b0 = a0 + run;
+        const int diag = VT * (tid - first);
+        auto A = [&](i64 i) { return skey[pos16(a0 + (int)i)]; };
+        auto B = [&](i64 j) { return skey[pos16(b0 + (int)j)]; };
+        const int ai = (int)merge_path(A, (i64)run, B, (i64)run, (i64)diag);
+        int srcs[VT];
+        serial_merge<VT>(skey, a0, run, b0, run, ai, diag - ai, VT, k, srcs);
+#pragma unroll
+        for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VT; ++i) {
+            const int e = tid * VT + i;
+            skey[pos16(e)] = k[i];
+            sidx[pos16(e)] = ix[i];
+        }
+        __syncthreads();
+    }
+
+    for (int e = tid; e < count; e += NT) {
+        keys[p * M + base + e] = skey[pos16(e)];
+        idx[p * M + base + e] = sidx[pos16(e)];
+    }
+    s1 = block_sum<NT>(s1, red);
+    s2 = block_sum<NT>(s2, red);
+    bad = block_sum<NT>(bad, red);
+    if (tid == 0) {
+        double* o = part + (p * ntiles + tile) * 4;
+        o[0] = s1; o[1] = s2; o[2] = bad; o[3] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge pass.  FOLD == false: merges pairs of sorted runs of length R (merge sort pass).
+// FOLD == true : produces the ascending order of |x - med| from the ascending order of x with a
+// single merge: the values below the median, walked downwards (med - x, non-decreasing because
+// rounding is monotone), against the values at or above it (x - med).  This replaces the second
+// full sort of src/mcmc_ref/diagnostics.py:93-98 + :110.  Each workgroup owns OB = NT*VT outputs.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int VT, bool FOLD>
+__global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
+                                              double* __restrict__ kout, u32* __restrict__ iout, i64 M,
+                                              i64 R, const double* __restrict__ res, i64 P,
+                                              const i64* __restrict__ split)
+{
+    constexpr int OB = NT * VT;
+    constexpr int TP = OB + OB / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* skey = reinterpret_cast<double*>(smem);
+    u32* sidx = reinterpret_cast<u32*>(skey + TP);
+    i64* sh = reinterpret_cast<i64*>(sidx + TP);
+
+    const int tid = threadIdx.x;
+    const i64 p = blockIdx.y;
+    const i64 o0 = (i64)blockIdx.x * OB;
+    if (o0 >= M) return;
+    const double* kp = kin + p * M;
+    const u32* ip = iin + p * M;
+
+    i64 abase, na, bbase, nb, d0;
+    double med = 0.0;
+    if (!FOLD) {
+        const i64 pb = (o0 / (2 * R)) * (2 * R);
+        abase = pb;
+        na = (M - pb < R) ? M - pb : R;
+        bbase = pb + na;
+        nb = (M - bbase < R) ? M - bbase : R;
+        d0 = o0 - pb;
+    } else {
+        const i64 s = split[p];
+        med = res[R_MEDIAN * P + p];
+        abase = s - 1;  // walked downwards
+        na = s;
+        bbase = s;
+        nb = M - s;
+        d0 = o0;
+    }
+    const i64 tot = na + nb;
+    const i64 d1 = (d0 + OB < tot) ? d0 + OB : tot;
+
+    auto GA = [&](i64 i) -> double { return FOLD ? med - kp[abase - i] : kp[abase + i]; };
+    auto GB = [&](i64 j) -> double { return FOLD ? kp[bbase + j] - med : kp[bbase + j]; };
+    if (tid == 0) sh[0] = merge_path(GA, na, GB, nb, d0);
+    if (tid == 64) sh[1] = merge_path(GA, na, GB, nb, d1);
+    __syncthreads();
+    const i64 ai0 = sh[0], ai1 = sh[1];
+    const i64 bi0 = d0 - ai0;
+    const int ca = (int)(ai1 - ai0), cb = (int)((d1 - ai1) - bi0);
+    const int total = ca + cb;
+
+    for (int e = tid; e < total; e += NT) {
+        double v; u32 id;
+        if (e < ca) {
+            const i64 g = FOLD ? abase - (ai0 + e) : abase + ai0 + e;
+            v = FOLD ? med - kp[g] : kp[g];
+            id = ip[g];
+        } else {
+            const i64 g = bbase + bi0 + (e - ca);
+            v = FOLD ? kp[g] - med : kp[g];
+            id = ip[g];
+        }
+        skey[pos16(e)] = v;
+        sidx[pos16(e)] = id;
+    }
+    __syncthreads();
+
+    const int diag = (tid * VT < total) ? tid * VT : total;
+    const int nout = (total - diag < VT) ? total - diag : VT;
+    auto A = [&](i64 i) { return skey[pos16((int)i)]; };
+    auto B = [&](i64 j) { return skey[pos16(ca + (int)j)]; };
+    const int ai = (int)merge_path(A, (i64)ca, B, (i64)cb, (i64)diag);
+    double k[VT];
+    int srcs[VT];
+    u32 ix[VT];
+    serial_merge<VT>(skey, 0, ca, ca, cb, ai, diag - ai, nout, k, srcs);
+#pragma unroll
+    for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        if (i < nout) {
+            skey[pos16(diag + i)] = k[i];
+            sidx[pos16(diag + i)] = ix[i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < total; e += NT) {
+        kout[p * M + o0 + e] = skey[pos16(e)];
+        iout[p * M + o0 + e] = sidx[pos16(e)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Order statistics from the pooled ascending keys: quantiles (numpy `linear` lerp, which pyarrow's
+// interpolation="linear" agrees with to 1 ulp; src/mcmc_ref/backends_numpy.py:44,
+// backends_arrow.py:40-42), statistics.median (diagnostics.py:97) and the fold split point
+// s = #(x < med).  One thread per parameter.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_order_stats(const double* __restrict__ keys, i64 M, i64 P, QArgs q,
+                              double* __restrict__ res, i64* __restrict__ split)
+{
+#pragma clang fp contract(off)  // the lerp must round like numpy's (separate multiply and add)
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double* k = keys + p * M;
+    for (int j = 0; j < q.nq; ++j) {
+        const i64 lo = q.lo[j], hi = (lo + 1 < M) ? lo + 1 : M - 1;
+        const double a = k[lo], b = k[hi], d = b - a, g = q.g[j];
+        res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
+    }
+    const double med = (M & 1) ? k[M / 2] : (k[M / 2 - 1] + k[M / 2]) / 2.0;
+    res[R_MEDIAN * P + p] = med;
+    i64 lo = 0, hi = M;  // first index with k[i] >= med
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if (k[mid] < med) lo = mid + 1; else hi = mid;
+    }
+    split[p] = lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ranks -> z.  For the sorted position i of a parameter: the maximal run [s, e) of equal keys
+// gets the average 1-based rank (s + 1 + e) / 2 (src/mcmc_ref/diagnostics.py:113-122),
+// z = Phi^-1((rank - 0.5) / M) (:130-131), written to the draw's pooled (time-order) position.
+// Run ends are found by galloping + bisection from i, so isolated values cost two neighbour
+// loads and long tie runs cost O(log run).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
+                                                const u32* __restrict__ idx, i64 M,
+                                                double* __restrict__ z, double* __restrict__ rank_out)
+{
+    const i64 p = blockIdx.y;
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const double* k = keys + p * M;
+    const double v = k[i];
+    i64 s = i, e = i + 1;
+    if (i > 0 && k[i - 1] == v) {  // gallop left: find first index with key == v
+        i64 step = 1, hi = i - 1;  // k[hi] == v
+        i64 lo = hi - step;
+        while (lo >= 0 && k[lo] == v) { hi = lo; step <<= 1; lo = hi - step; }
+        if (lo < -1) lo = -1;      // k[lo] != v (or lo == -1), k[hi] == v
+        while (hi - lo > 1) {
+            const i64 mid = (lo + hi) >> 1;
+            if (k[mid] == v) hi = mid; else lo = mid;
+        }
+        s = hi;
+    }
+    if (i + 1 < M && k[i + 1] == v) {  // gallop right: find last index with key == v
+        i64 step = 1, lo = i + 1;      // k[lo] == v
+        i64 hi = lo + step;
+        while (hi < M && k[hi] == v) { lo = hi; step <<= 1; hi = lo + step; }
+        if (hi > M) hi = M;            // k[hi] != v (or hi == M), k[lo] == v
+        while (hi - lo > 1) {
+            const i64 mid = (lo + hi) >> 1;
+            if (k[mid] == v) lo = mid; else hi = mid;
+        }
+        e = lo + 1;
+    }
+    const double r = (double)(s + 1 + e) / 2.0;
+    const double pr = (r - 0.5) / (double)M;
+    const u32 t = idx[p * M + i];
+    z[p * M + t] = inv_cdf(pr);
+    if (rank_out) rank_out[p * M + t] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split R-hat and ESS of one (parameter, kind) from z in time order.  blockIdx.y: 0 = bulk z,
+// 1 = folded z.  Chain c is z[off[c] .. off[c+1]); n = min chain length, nh = min half length
+// (over chains with at least 2 draws), as the reference truncates (diagnostics.py:140, :158).
+//   _split_chains + _rhat   src/mcmc_ref/diagnostics.py:76-85, 136-151
+//   _ess + _autocorr        src/mcmc_ref/diagnostics.py:154-193  (UNSPLIT chains, lag loop
+//                           stops at the first negative rho; rho normalised by (n - lag))
+// Lags are evaluated in blocks (16 first, then 64): lane = (lag, i-phase), the deviations of one
+// chain are staged in LDS (STAGE) or read through L2 (long chains).  The rho terms of a block
+// are then accumulated left-to-right by one thread, exactly like the reference's loop.
+// ------------------------------------------------------------------------------------------------
+template <int NT, bool STAGE>
+__global__ __launch_bounds__(NT) void k_diag(const double* __restrict__ zb, const double* __restrict__ zt,
+                                             i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
+                                             double* __restrict__ res, i64 P)
+{
+    constexpr int NW = NT / kWave;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);  // NW
+    double* cm = red + NW;                           // C   chain means
+    double* cv = cm + C;                             // C   chain variances (ddof=1)
+    double* hm = cv + C;                             // 2C  half-chain means
+    double* hv = hm + 2 * C;                         // 2C  half-chain variances
+    double* tot = hv + 2 * C;                        // 64  per-lag totals
+    double* wred = tot + 64;                         // NW*64
+    double* ctl = wred + NW * 64;                    // 4: var_hat, run flag
+    double* dch = ctl + 4;                           // n (STAGE only)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 p = blockIdx.x;
+    const int kind = blockIdx.y;
+    const double* z = (kind ? zt : zb) + p * M;
+    const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
+    const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
+    const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
+
+    // ---- per-chain and per-half means / variances (two-pass, like _variance) ----
+    for (int c = 0; c < C; ++c) {
+        const double* zc = z + off[c];
+        const i64 nc = off[c + 1] - off[c], hc = nc / 2;
+        double sf = 0.0, s0 = 0.0, s1 = 0.0;
+        for (i64 i = tid; i < n; i += NT) sf += zc[i];
+        if (hc > 0) {
+            for (i64 i = tid; i < nh; i += NT) { s0 += zc[i]; s1 += zc[hc + i]; }
+        }
+        sf = block_sum<NT>(sf, red);
+        s0 = block_sum<NT>(s0, red);
+        s1 = block_sum<NT>(s1, red);
+        const double mf = (n > 0) ? sf / (double)n : 0.0;
+        const double m0 = (nh > 0) ? s0 / (double)nh : 0.0, m1 = (nh > 0) ? s1 / (double)nh : 0.0;
+        double qf = 0.0, q0 = 0.0, q1 = 0.0;
+        for (i64 i = tid; i < n; i += NT) { const double d = zc[i] - mf; qf = fma(d, d, qf); }
+        if (hc > 0) {
+            for (i64 i = tid; i < nh; i += NT) {
+                const double d0 = zc[i] - m0, d1 = zc[hc + i] - m1;
+                q0 = fma(d0, d0, q0); q1 = fma(d1, d1, q1);
+            }
+        }
+        qf = block_sum<NT>(qf, red);
+        q0 = block_sum<NT>(q0, red);
+        q1 = block_sum<NT>(q1, red);
+        if (tid == 0) {
+            cm[c] = mf;
+            cv[c] = (n >= 2) ? qf / (double)(n - 1) : 0.0;
+            hm[2 * c] = m0; hm[2 * c + 1] = m1;
+            hv[2 * c] = (nh >= 2) ? q0 / (double)(nh - 1) : 0.0;
+            hv[2 * c + 1] = (nh >= 2) ? q1 / (double)(nh - 1) : 0.0;
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        // ---- split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped ----
+        int ms = 0;
+        for (int c = 0; c < C; ++c) ms += (off[c + 1] - off[c] >= 2) ? 2 : 0;
+        double rhat;
+        if (ms < 2 || nh < 2) {
+            rhat = NAN;
+        } else {
+            double st = 0.0;
+            for (int c = 0; c < C; ++c)
+                if (off[c + 1] - off[c] >= 2) { st += hm[2 * c]; st += hm[2 * c + 1]; }
+            const double mt = st / (double)ms;
+            double sb = 0.0, sw = 0.0;
+            for (int c = 0; c < C; ++c)
+                if (off[c + 1] - off[c] >= 2) {
+                    const double a = hm[2 * c] - mt, b = hm[2 * c + 1] - mt;
+                    sb += a * a; sb += b * b;
+                    sw += hv[2 * c]; sw += hv[2 * c + 1];
+                }
+            const double vb = (double)nh * sb / (double)(ms - 1);
+            const double vw = sw / (double)ms;
+            const double vh = (double)(nh - 1) / (double)nh * vw + vb / (double)nh;
+            rhat = (vw == 0.0) ? ((vb == 0.0) ? 1.0 : INFINITY) : sqrt(vh / vw);
+        }
+        res[f_rhat * P + p] = rhat;
+        // ---- ESS prologue (diagnostics.py:154-169) ----
+        double run = 0.0, vh = 0.0;
+        if (C == 0 || n < 2) {
+            res[f_ess * P + p] = NAN;
+            res[f_lag * P + p] = 0.0;
+        } else {
+            double st = 0.0;
+            for (int c = 0; c < C; ++c) st += cm[c];
+            const double mt = st / (double)C;
+            double sb = 0.0, sw = 0.0;
+            for (int c = 0; c < C; ++c) { const double a = cm[c] - mt; sb += a * a; sw += cv[c]; }
+            const double vb = (C > 1) ? (double)n * sb / (double)(C - 1) : 0.0;
+            const double vw = sw / (double)C;
+            vh = (double)(n - 1) / (double)n * vw + vb / (double)n;
+            if (vh == 0.0) {
+                res[f_ess * P + p] = (double)((i64)C * n);
+                res[f_lag * P + p] = 0.0;
+            } else {
+                run = 1.0;
+            }
+        }
+        ctl[0] = vh; ctl[1] = run;
+    }
+    __syncthreads();
+    if (ctl[1] == 0.0) return;
+    const double vhat = ctl[0];
+
+    double rho_sum = 0.0;  // thread 0 only
+    i64 terms = 0;
+    i64 lag0 = 1;
+    int LB = 16;
+    while (lag0 < n) {
+        const int nl = (int)((n - lag0 < (i64)LB) ? n - lag0 : (i64)LB);
+        const int ll = lane % LB, r = lane / LB, stride = kWave / LB;
+        const i64 lag = lag0 + ll;
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double* zc = z + off[c];
+            const double mean = cm[c];
+            if (STAGE) {
+                __syncthreads();
+                for (i64 i = tid; i < n; i += NT) dch[i] = zc[i] - mean;
+                __syncthreads();
+            }
+            if (ll < nl) {
+                for (i64 i = (i64)w * stride + r; i + lag < n; i += (i64)NW * stride) {
+                    const double a = STAGE ? dch[i] : zc[i] - mean;
+                    const double b = STAGE ? dch[i + lag] : zc[i + lag] - mean;
+                    acc = fma(a, b, acc);
+                }
+            }
+        }
+        for (int o = LB; o < kWave; o <<= 1) acc += __shfl_xor(acc, o, kWave);
+        __syncthreads();
+        if (lane < LB) wred[w * 64 + lane] = acc;
+        __syncthreads();
+        if (tid < nl) {
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
+            tot[tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double stop = 0.0;
+            for (int l = 0; l < nl; ++l) {
+                const double cov = tot[l] / (double)(n - (lag0 + l));
+                const double rho = cov / ((double)C * vhat);
+                if (rho < 0.0) { stop = 1.0; break; }
+                rho_sum += rho;
+                ++terms;
+            }
+            ctl[2] = stop;
+        }
+        __syncthreads();
+        if (ctl[2] != 0.0) break;
+        lag0 += nl;
+        LB = 64;
+    }
+    if (tid == 0) {
+        res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+        res[f_lag * P + p] = (double)terms;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finalize: pooled mean / population std from the tile partials, rhat = Python max(bulk, tail)
+// (`tail if tail > bulk else bulk`, src/mcmc_ref/diagnostics.py:40), NaN diagnostics when there
+// are fewer than two chains (diagnostics.py:29-30, 53-54, 69-70).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const double* __restrict__ X,
+                           i64 P, int C, double* __restrict__ res)
+{
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double s1 = 0.0, s2 = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double* o = part + (p * S + s) * 4;
+        s1 += o[0]; s2 += o[1]; b += o[2];
+    }
+    const double K = X[p * M], m = (double)M, mu = s1 / m;
+    double var = (s2 - s1 * mu) / m;
+    if (var < 0.0) var = 0.0;
+    res[R_MEAN * P + p] = K + mu;
+    res[R_STD * P + p] = sqrt(var);
+    res[R_BAD * P + p] = b;
+    if (C < 2) {
+        res[R_RHAT * P + p] = NAN; res[R_RHAT_BULK * P + p] = NAN; res[R_RHAT_TAIL * P + p] = NAN;
+        res[R_ESS_BULK * P + p] = NAN; res[R_ESS_TAIL * P + p] = NAN;
+        res[R_LAG_BULK * P + p] = 0.0; res[R_LAG_TAIL * P + p] = 0.0;
+    } else {
+        const double rb = res[R_RHAT_BULK * P + p], rt = res[R_RHAT_TAIL * P + p];
+        res[R_RHAT * P + p] = (rt > rb) ? rt : rb;
+    }
+}
+
+// compare.compare_stats arithmetic (src/mcmc_ref/compare.py:41-43)
+__global__ void k_compare(const double* __restrict__ ref, const double* __restrict__ act, i64 n,
+                          double tol, double* __restrict__ rel, unsigned char* __restrict__ pass)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double r = ref[i], a = act[i], ar = fabs(r);
+    const double denom = (1e-12 > ar) ? 1e-12 : ar;  // Python max(abs(ref), 1e-12): NaN stays NaN
+    const double e = fabs(a - r) / denom;
+    rel[i] = e;
+    pass[i] = (e <= tol) ? 1 : 0;
+}
+
+// Synthetic stress tensor: iid N(p, sigma_p), counter-based, layout [P][C][N].
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_synth(T* __restrict__ out, i64 total, i64 M, u64 seed)
+{
+    const i64 stride = (i64)gridDim.x * 256;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const i64 p = i / M;
+        const u64 base = seed * 0x9E3779B97F4A7C15ull + 2ull * (u64)i;
+        const u64 h1 = splitmix64(base), h2 = splitmix64(base + 1);
+        const double u1 = ((double)(h1 >> 11) + 0.5) * 0x1.0p-53;
+        const double u2 = (double)(h2 >> 11) * 0x1.0p-53;
+        const double e = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+        int k = (int)(p % 7) - 3;
+        double sigma = 1.0;
+        for (; k > 0; --k) sigma *= 10.0;
+        for (; k < 0; ++k) sigma /= 10.0;
+        out[i] = (T)((double)p + sigma * e);
+    }
+}
+
+}  // namespace mcr

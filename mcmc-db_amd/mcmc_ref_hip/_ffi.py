@@ -1,0 +1,374 @@
+"""ctypes binding of libmcmcref_hip.so (include/mcmcref_hip.h).  No torch, no fallback.
+
+If the shared library or a HIP device is missing every entry point raises
+`HipUnavailableError`: the product path never silently computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import threading
+from pathlib import Path
+
+import numpy as np
+
+MCR_OK = 0
+MCR_EINVAL, MCR_EMINCHAINS, MCR_EMINCHAINS_ARG, MCR_ENONFINITE = -1, -2, -3, -4
+MCR_EHIP, MCR_ENOMEM, MCR_ENODEVICE, MCR_ECOMM = -5, -6, -7, -8
+MCR_F64, MCR_F32 = 0, 1
+MCR_MAX_QUANTILES = 32
+MCR_MAX_INFLIGHT = 4
+
+_PKG = Path(__file__).resolve().parent
+DEFAULT_LIB = _PKG.parent / "lib" / "libmcmcref_hip.so"
+
+
+class HipUnavailableError(RuntimeError):
+    """libmcmcref_hip.so could not be loaded, or no MI355X/HIP device is usable."""
+
+
+class McrError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[mcr {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+class Summary(C.Structure):
+    _fields_ = [(n, _dp) for n in ("mean", "std", "q", "median", "rhat", "rhat_bulk", "rhat_tail",
+                                   "ess_bulk", "ess_tail")] + \
+               [("lag_bulk", _ip), ("lag_tail", _ip), ("q_lo", _ip)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+# every symbol include/mcmcref_hip.h declares: (restype, argtypes)
+_I64 = C.c_int64
+_TENSOR = [C.c_void_p, C.c_int, _I64, _I64, _I64, _I64, _I64, _I64]
+SYMBOLS = {
+    "mcr_version": (C.c_int, []),
+    "mcr_device_count": (C.c_int, []),
+    "mcr_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mcr_free": (None, [C.c_void_p]),
+    "mcr_last_error": (C.c_char_p, [C.c_void_p]),
+    "mcr_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mcr_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mcr_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mcr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mcr_sync": (C.c_int, [C.c_void_p]),
+    "mcr_summarize": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
+    "mcr_summarize_dev": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
+    "mcr_summarize_enqueue": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
+    "mcr_summarize_wait": (C.c_int, [C.c_void_p]),
+    "mcr_diagnose_chains": (C.c_int, [C.c_void_p, _dp, _ip, C.c_int, C.c_int, C.POINTER(Summary),
+                                      _dp, _dp, _dp, _dp]),
+    "mcr_basic_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _dp, _dp]),
+    "mcr_moments_dev": (C.c_int, [C.c_void_p] + _TENSOR + [_dp, _dp]),
+    "mcr_compare": (C.c_int, [C.c_void_p, _dp, _dp, _I64, C.c_double, _dp, C.POINTER(C.c_uint8)]),
+    "mcr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcr_profile_reset": (C.c_int, [C.c_void_p]),
+    "mcr_profile_get": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
+    "mcr_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _I64, _I64, C.c_uint64]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("MCMC_REF_HIP_LIB", str(DEFAULT_LIB)))
+
+
+def load_library():
+    """dlopen the C ABI and bind every declared symbol (works without a GPU)."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            path = lib_path()
+            if not path.exists():
+                raise HipUnavailableError(
+                    f"{path} not found: build it with `python mcmc-db_amd/build.py` "
+                    "(there is no CPU fallback)")
+            try:
+                L = C.CDLL(str(path))
+            except OSError as exc:
+                raise HipUnavailableError(f"cannot load {path}: {exc}") from exc
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(L, name)   # AttributeError if the ABI is incomplete
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def _as_dp(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _as_ip(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+SUMMARY_F64 = ("mean", "std", "median", "rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail")
+
+
+class SummaryBuffers:
+    """Host arrays an mcr_summary points into (kept alive by this object)."""
+
+    def __init__(self, P: int, nq: int):
+        self.P, self.nq = P, nq
+        n = max(P, 1)
+        self.arrays = {k: np.full(n, np.nan) for k in SUMMARY_F64}
+        self.arrays["q"] = np.full(max(P * nq, 1), np.nan)
+        self.arrays["lag_bulk"] = np.zeros(n, dtype=np.int64)
+        self.arrays["lag_tail"] = np.zeros(n, dtype=np.int64)
+        self.arrays["q_lo"] = np.zeros(max(nq, 1), dtype=np.int64)
+        kw = {k: _as_dp(self.arrays[k]) for k in SUMMARY_F64 + ("q",)}
+        kw.update({k: _as_ip(self.arrays[k]) for k in ("lag_bulk", "lag_tail", "q_lo")})
+        self.struct = Summary(**kw)
+
+    def result(self) -> dict:
+        P, nq = self.P, self.nq
+        out = {k: self.arrays[k][:P].copy() for k in SUMMARY_F64 + ("lag_bulk", "lag_tail")}
+        out["q"] = self.arrays["q"][:P * nq].reshape(P, nq).copy()
+        out["q_lo"] = self.arrays["q_lo"][:nq].copy()
+        return out
+
+
+def tensor_args(draws: np.ndarray, layout: str):
+    """(dtype code, C, N, P, stride_c, stride_n, stride_p) for a 3-D array whose axes are `layout`."""
+    if draws.ndim != 3 or sorted(layout) != ["c", "n", "p"]:
+        raise ValueError("draws must be 3-D and layout a permutation of 'cnp'")
+    if draws.dtype == np.float64:
+        code = MCR_F64
+    elif draws.dtype == np.float32:
+        code = MCR_F32
+    else:
+        raise TypeError(f"unsupported dtype {draws.dtype}; use float64 or float32")
+    ax = {a: i for i, a in enumerate(layout)}
+    dims = [draws.shape[ax[a]] for a in "cnp"]
+    strides = [draws.strides[ax[a]] // draws.itemsize for a in "cnp"]
+    if any(s < 0 for s in strides):
+        raise ValueError("negative strides are not supported")
+    return (code, *dims, *strides)
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = C.c_void_p()
+        ctx._check(ctx.lib.mcr_dev_alloc(ctx.handle, nbytes, C.byref(self.ptr)))
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.mcr_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data_as(C.c_void_p),
+                                                    arr.nbytes))
+        return self
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        self.ctx._check(self.ctx.lib.mcr_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.ptr,
+                                                    out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mcr_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = C.c_void_p()
+
+
+class DeviceTensor:
+    """A draw tensor resident in HBM: device buffer + the (dtype, dims, strides) it was uploaded with."""
+
+    def __init__(self, ctx: "Context", buf: DeviceBuffer, targs):
+        self.ctx, self.buf, self.targs = ctx, buf, targs
+
+    @property
+    def shape_cnp(self):
+        return self.targs[1:4]
+
+    def free(self):
+        self.buf.free()
+
+
+class Context:
+    """One GPU + one HIP stream (mcr_ctx).  Not thread-safe: one Context per thread."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("MCMC_REF_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = C.c_void_p()
+        rc = self.lib.mcr_init(int(device), C.byref(h))
+        if rc != MCR_OK:
+            msg = (self.lib.mcr_last_error(None) or b"").decode()
+            if rc == MCR_ENODEVICE:
+                raise HipUnavailableError(msg)
+            raise McrError(rc, msg)
+        self.handle = h
+        self.device = int(device)
+        self._pending: list[SummaryBuffers] = []
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mcr_free(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- errors ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != MCR_OK:
+            raise McrError(rc, (self.lib.mcr_last_error(self.handle) or b"").decode())
+
+    # -- device memory --------------------------------------------------------------------------
+    def upload(self, draws: np.ndarray, layout: str = "pcn") -> DeviceTensor:
+        targs = tensor_args(draws, layout)
+        if not draws.flags.c_contiguous:
+            raise ValueError("upload() needs a C-contiguous array (permute the layout string instead)")
+        buf = DeviceBuffer(self, max(draws.nbytes, 8)).upload(draws)
+        return DeviceTensor(self, buf, targs)
+
+    def alloc_tensor(self, C_: int, N: int, P: int, dtype=np.float64) -> DeviceTensor:
+        """Uninitialised [P][C][N] device tensor (fill it with fill_synthetic)."""
+        es = np.dtype(dtype).itemsize
+        buf = DeviceBuffer(self, max(C_ * N * P * es, 8))
+        code = MCR_F64 if np.dtype(dtype) == np.float64 else MCR_F32
+        return DeviceTensor(self, buf, (code, C_, N, P, N, 1, C_ * N))
+
+    def fill_synthetic(self, t: DeviceTensor, seed: int = 4711):
+        code, C_, N, P = t.targs[:4]
+        self._check(self.lib.mcr_fill_synthetic(self.handle, t.buf.ptr, code, C_, N, P, seed))
+
+    def sync(self):
+        self._check(self.lib.mcr_sync(self.handle))
+
+    # -- hot path -----------------------------------------------------------------------------
+    @staticmethod
+    def _quantiles(quantiles):
+        qs = np.ascontiguousarray(list(quantiles), dtype=np.float64)
+        if qs.size > MCR_MAX_QUANTILES:
+            raise ValueError(f"at most {MCR_MAX_QUANTILES} quantiles")
+        return qs
+
+    def summarize(self, draws, layout: str = "pcn", min_chains: int = 4,
+                  quantiles=(0.05, 0.5, 0.95)) -> dict:
+        """All per-parameter statistics of a host array or a DeviceTensor (synchronous)."""
+        qs = self._quantiles(quantiles)
+        if isinstance(draws, DeviceTensor):
+            targs, ptr, fn = draws.targs, draws.buf.ptr, self.lib.mcr_summarize_dev
+        else:
+            targs, fn = tensor_args(draws, layout), self.lib.mcr_summarize
+            ptr = draws.ctypes.data_as(C.c_void_p)
+        bufs = SummaryBuffers(targs[3], qs.size)
+        self._check(fn(self.handle, ptr, *targs, int(min_chains), _as_dp(qs), qs.size, C.byref(bufs.struct)))
+        return bufs.result()
+
+    def enqueue(self, t: DeviceTensor, min_chains: int = 4, quantiles=(0.05, 0.5, 0.95)) -> SummaryBuffers:
+        qs = self._quantiles(quantiles)
+        bufs = SummaryBuffers(t.targs[3], qs.size)
+        self._check(self.lib.mcr_summarize_enqueue(self.handle, t.buf.ptr, *t.targs, int(min_chains), _as_dp(qs),
+                                                   qs.size, C.byref(bufs.struct)))
+        self._pending.append(bufs)
+        return bufs
+
+    def wait(self):
+        try:
+            self._check(self.lib.mcr_summarize_wait(self.handle))
+        finally:
+            self._pending.clear()
+
+    def diagnose_chains(self, chains, min_chains: int = 4, debug: bool = False) -> dict:
+        """split_rhat / ess_bulk / ess_tail of ONE parameter given as (possibly ragged) chains."""
+        off = np.zeros(len(chains) + 1, dtype=np.int64)
+        for i, c in enumerate(chains):
+            off[i + 1] = off[i] + len(c)
+        M = int(off[-1])
+        pooled = np.empty(max(M, 1), dtype=np.float64)
+        for i, c in enumerate(chains):
+            pooled[off[i]:off[i + 1]] = np.asarray(c, dtype=np.float64)
+        bufs = SummaryBuffers(1, 0)
+        dbg = [np.full(max(M, 1), np.nan) for _ in range(4)] if debug else [None] * 4
+        self._check(self.lib.mcr_diagnose_chains(self.handle, _as_dp(pooled), _as_ip(off), len(chains),
+                                                 int(min_chains), C.byref(bufs.struct), *[_as_dp(d) for d in dbg]))
+        r = bufs.result()
+        out = {k: (float(r[k][0]) if k in SUMMARY_F64 else int(r[k][0]))
+               for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail", "median", "lag_bulk",
+                         "lag_tail")}
+        if debug:
+            for name, d in zip(("z_bulk", "z_tail", "rank_bulk", "rank_tail"), dbg):
+                out[name] = [d[off[i]:off[i + 1]].copy() for i in range(len(chains))]
+        return out
+
+    def basic_stats(self, values) -> dict:
+        v = np.ascontiguousarray(values)
+        if v.dtype not in (np.float64, np.float32):
+            v = v.astype(np.float64)
+        mean, std = C.c_double(math.nan), C.c_double(math.nan)
+        code = MCR_F64 if v.dtype == np.float64 else MCR_F32
+        self._check(self.lib.mcr_basic_stats(self.handle, v.ctypes.data_as(C.c_void_p), code, v.size,
+                                             C.byref(mean), C.byref(std)))
+        return {"mean": mean.value, "std": std.value}
+
+    def moments(self, t: DeviceTensor) -> tuple[np.ndarray, np.ndarray]:
+        P = t.targs[3]
+        mean, std = np.full(max(P, 1), np.nan), np.full(max(P, 1), np.nan)
+        self._check(self.lib.mcr_moments_dev(self.handle, t.buf.ptr, *t.targs, _as_dp(mean), _as_dp(std)))
+        return mean[:P], std[:P]
+
+    def compare(self, ref, actual, tol: float):
+        r = np.ascontiguousarray(ref, dtype=np.float64)
+        a = np.ascontiguousarray(actual, dtype=np.float64)
+        if r.shape != a.shape:
+            raise ValueError("ref and actual must have the same shape")
+        rel = np.empty(max(r.size, 1))
+        ok = np.zeros(max(r.size, 1), dtype=np.uint8)
+        self._check(self.lib.mcr_compare(self.handle, _as_dp(r), _as_dp(a), r.size, float(tol), _as_dp(rel),
+                                         ok.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return rel[:r.size], ok[:r.size].astype(bool)
+
+    # -- measurement -----------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self.lib.mcr_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.mcr_profile_reset(self.handle))
+
+    def profile_get(self) -> dict:
+        arr = (KernelTime * 32)()
+        n = C.c_int(0)
+        self._check(self.lib.mcr_profile_get(self.handle, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms)}
+                for i in range(min(n.value, 32))}
+
+
+_default_ctx: Context | None = None
+_ctx_lock = threading.Lock()
+
+
+def default_context() -> Context:
+    """Process-wide Context on MCMC_REF_HIP_DEVICE / LOCAL_RANK / device 0."""
+    global _default_ctx
+    with _ctx_lock:
+        if _default_ctx is None:
+            _default_ctx = Context()
+        return _default_ctx

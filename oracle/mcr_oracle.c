@@ -259,11 +259,17 @@ ORC_API int orc_diag(const double* x, const int64_t* off, int C, int min_chains,
     if (min_chains < 1) return -3;
     if (C < min_chains) return -2;
     out->lag_bulk = out->lag_tail = 0; out->median = NAN;
+    int64_t M = C > 0 ? off[C] : 0;
     if (C < 2) {
         out->rhat = out->rhat_bulk = out->rhat_tail = out->ess_bulk = out->ess_tail = NAN;
+        if (M > 0) {                       /* the median is still a pooled order statistic */
+            double* t = (double*)malloc(sizeof(double) * (size_t)M);
+            if (!t) return -1;
+            orc_fold(x, M, t, &out->median);
+            free(t);
+        }
         return 0;
     }
-    int64_t M = off[C];
     double* z = (double*)malloc(sizeof(double) * (size_t)(M > 0 ? M : 1));
     double* f = (double*)malloc(sizeof(double) * (size_t)(M > 0 ? M : 1));
     if (!z || !f) { free(z); free(f); return -1; }

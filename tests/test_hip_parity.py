@@ -1,0 +1,240 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the committed goldens.
+
+Gates (BASELINE.json north_star): integer / rank / index outputs bit-exact; floating-point
+outputs within 1e-6 relative (we assert much tighter where the arithmetic allows).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+from conftest import MODEL_NAMES, load_json, load_model
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6          # north_star tolerance for floating-point outputs
+TIGHT = 1e-9        # what fp64 on both sides actually delivers for these statistics
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mcmc_ref_hip import _ffi
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def close(a, b, rel, scale=0.0):
+    a, b = float(a), float(b)
+    if math.isnan(a) or math.isnan(b):
+        return math.isnan(a) and math.isnan(b)
+    if math.isinf(a) or math.isinf(b):
+        return a == b
+    return abs(a - b) <= rel * max(abs(a), abs(b)) + scale
+
+
+def check_summary(got, exp, rel=TIGHT, what=""):
+    P = len(exp["mean"])
+    for p in range(P):
+        sd = float(exp["std"][p])
+        # a mean is a cancelling sum: its error scales with the spread, not with |mean|
+        assert close(got["mean"][p], exp["mean"][p], rel, scale=rel * sd), (what, p, "mean")
+        assert close(got["std"][p], exp["std"][p], rel), (what, p, "std", got["std"][p], exp["std"][p])
+        assert close(got["median"][p], exp["median"][p], 0.0), (what, p, "median")
+        for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
+            assert close(got[k][p], exp[k][p], rel), (what, p, k, got[k][p], exp[k][p])
+        assert int(got["lag_bulk"][p]) == int(exp["lag_bulk"][p]), (what, p, "lag_bulk")
+        assert int(got["lag_tail"][p]) == int(exp["lag_tail"][p]), (what, p, "lag_tail")
+    # quantiles are order statistics + one lerp: bit-exact
+    assert np.array_equal(got["q"], exp["q"]), what
+
+
+def test_version_and_device(ctx):
+    assert ctx.lib.mcr_version() == 100
+    assert ctx.lib.mcr_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", MODEL_NAMES)
+def test_packaged_models_vs_oracle_and_goldens(ctx, oracle, name):
+    draws, params, rec = load_model(name)
+    got = ctx.summarize(draws, "pcn")
+    exp = oracle.summarize(draws, "pcn")
+    check_summary(got, exp, what=name)
+    # the reference's own packaged goldens and the imported-reference vectors
+    for i, p in enumerate(params):
+        for k in ("rhat", "ess_bulk", "ess_tail"):
+            assert close(got[k][i], rec["meta_diagnostics"][p][k], REL)
+            assert close(got[k][i], rec["recomputed"][p][k], TIGHT)
+        assert int(got["lag_bulk"][i]) == rec["recomputed"][p]["lag_bulk"]
+        assert int(got["lag_tail"][i]) == rec["recomputed"][p]["lag_tail"]
+        for b in ("arrow", "numpy"):
+            st = rec["stats"][b][p]
+            assert close(got["mean"][i], st["mean"], TIGHT, scale=TIGHT * st["std"])
+            assert close(got["std"][i], st["std"], TIGHT)
+            for j, qk in enumerate(("q5", "q50", "q95")):
+                assert close(got["q"][i, j], st[qk], 1e-14)
+        assert [float(v) for v in got["q"][i]] == [rec["stats"]["numpy"][p][qk] for qk in ("q5", "q50", "q95")]
+
+
+def test_eight_schools_c0_four_chains(ctx, oracle):
+    """BASELINE config 0: eight_schools chains 0-3 -> 4 x 1000 x 10."""
+    draws, params, _ = load_model("eight_schools-eight_schools_noncentered")
+    sub = np.ascontiguousarray(draws[:, :4, :])
+    check_summary(ctx.summarize(sub, "pcn"), oracle.summarize(sub, "pcn"), what="C0")
+    # the same tensor in Draws.to_numpy layout [C][N][P] and in f32
+    cnp = np.ascontiguousarray(np.transpose(sub, (1, 2, 0)))
+    check_summary(ctx.summarize(cnp, "cnp"), oracle.summarize(cnp, "cnp"), what="C0-cnp")
+    f32 = sub.astype(np.float32)
+    check_summary(ctx.summarize(f32, "pcn"), oracle.summarize(f32, "pcn"), what="C0-f32")
+
+
+def test_synth_c1_subset_vs_reference_goldens(ctx, oracle):
+    from mcmc_ref_hip import synth
+    g = load_json("synth_c1_subset.json")
+    x = synth.c1_model(g["C"], g["N"], g["P"], seed=g["seed"], params=g["params"])
+    got = ctx.summarize(x, "pcn")
+    check_summary(got, oracle.summarize(x, "pcn"), what="c1-subset")
+    for i, p in enumerate(g["params"]):
+        r = g["results"][str(p)]
+        for k in ("rhat", "ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail"):
+            assert close(got[k][i], r[k], TIGHT), (p, k)
+        assert (int(got["lag_bulk"][i]), int(got["lag_tail"][i])) == (r["lag_bulk"], r["lag_tail"])
+
+
+UNIT = load_json("unit_vectors.json")
+
+
+@pytest.mark.parametrize("name", [k for k in UNIT if not k.startswith("_")])
+def test_unit_vectors_ragged_api(ctx, name):
+    rec = UNIT[name]
+    chains = rec["chains"]
+    from mcmc_ref_hip._ffi import McrError, MCR_EMINCHAINS
+    for key, mc in (("min4", 4), ("min1", 1)):
+        exp = rec[key]
+        if isinstance(exp["rhat"], dict):
+            with pytest.raises(McrError) as ei:
+                ctx.diagnose_chains(chains, mc)
+            assert ei.value.code == MCR_EMINCHAINS
+            continue
+        got = ctx.diagnose_chains(chains, mc, debug=True)
+        for k in ("rhat", "ess_bulk", "ess_tail"):
+            assert close(got[k], exp[k], TIGHT), (name, key, k, got[k], exp[k])
+        if "rhat_bulk" in exp:
+            assert close(got["rhat_bulk"], exp["rhat_bulk"], TIGHT)
+            assert close(got["rhat_tail"], exp["rhat_tail"], TIGHT)
+            assert (got["lag_bulk"], got["lag_tail"]) == (exp["lag_bulk"], exp["lag_tail"]), (name, key)
+        if "z" in rec and len(chains) >= 1:
+            from scipy.stats import rankdata
+            flat = np.concatenate([np.asarray(c, dtype=float) for c in chains])
+            assert np.array_equal(np.concatenate(got["rank_bulk"]), rankdata(flat, method="average"))
+            fold = np.concatenate([np.asarray(c, dtype=float) for c in rec["folded"]])
+            assert np.array_equal(np.concatenate(got["rank_tail"]), rankdata(fold, method="average"))
+            for a, b in zip(got["z_bulk"], rec["z"]):
+                assert np.allclose(a, np.asarray(b), rtol=1e-13, atol=0)
+            for a, b in zip(got["z_tail"], rec["z_folded"]):
+                assert np.allclose(a, np.asarray(b), rtol=1e-13, atol=0)
+
+
+def test_error_codes(ctx):
+    from mcmc_ref_hip._ffi import McrError, MCR_EMINCHAINS, MCR_EMINCHAINS_ARG, MCR_ENONFINITE
+    x = np.random.default_rng(0).normal(size=(2, 3, 50))
+    with pytest.raises(McrError) as ei:
+        ctx.summarize(x, "pcn", min_chains=4)
+    assert ei.value.code == MCR_EMINCHAINS
+    with pytest.raises(McrError) as ei:
+        ctx.summarize(x, "pcn", min_chains=0)
+    assert ei.value.code == MCR_EMINCHAINS_ARG
+    x[1, 2, 7] = np.nan
+    with pytest.raises(McrError) as ei:
+        ctx.summarize(x, "pcn", min_chains=1)
+    assert ei.value.code == MCR_ENONFINITE
+    x[1, 2, 7] = np.inf
+    with pytest.raises(McrError) as ei:
+        ctx.summarize(x, "pcn", min_chains=1)
+    assert ei.value.code == MCR_ENONFINITE
+    # the context stays usable after an error
+    x[1, 2, 7] = 0.5
+    ctx.summarize(x, "pcn", min_chains=1)
+
+
+def test_shapes_edge_cases(ctx, oracle):
+    rng = np.random.default_rng(11)
+    for (P, C, N) in [(1, 4, 2), (3, 4, 3), (2, 4, 17), (5, 2, 64), (1, 1, 10), (2, 10, 1), (1, 4, 4097),
+                      (3, 5, 4096), (2, 4, 8193), (1, 3, 30001)]:
+        x = rng.normal(loc=2.0, scale=3.0, size=(P, C, N))
+        got = ctx.summarize(x, "pcn", min_chains=1)
+        exp = oracle.summarize(x, "pcn", min_chains=1)
+        check_summary(got, exp, what=f"{(P, C, N)}")
+    # empty tensors
+    got = ctx.summarize(np.zeros((2, 4, 0)), "pcn")
+    assert np.isnan(got["mean"]).all() and np.isnan(got["rhat"]).all() and np.isnan(got["ess_bulk"]).all()
+    got = ctx.summarize(np.zeros((0, 4, 10)), "pcn")
+    assert got["mean"].shape == (0,)
+
+
+def test_heavy_ties_and_constant(ctx, oracle):
+    rng = np.random.default_rng(5)
+    x = np.empty((4, 4, 3000))
+    x[0] = np.round(rng.normal(size=(4, 3000)), 1)            # ~60 distinct values, long tie runs
+    x[1] = rng.integers(0, 2, size=(4, 3000)).astype(float)   # two values
+    x[2] = 7.25                                               # constant: one run of length M
+    x[3] = np.round(rng.normal(size=(4, 3000)), 3)
+    x[3, 2] = 1.0                                             # one constant chain
+    check_summary(ctx.summarize(x, "pcn"), oracle.summarize(x, "pcn"), what="ties")
+
+
+def test_basic_stats_and_compare(ctx, oracle):
+    g = load_json("compare_cases.json")
+    for rec in g["basic"]:
+        out = ctx.basic_stats(rec["values"])
+        exp = rec["out"]
+        assert close(out["mean"], exp["mean"], 1e-12, scale=1e-12 * (exp["std"] if exp["std"] == exp["std"] else 0))
+        assert close(out["std"], exp["std"], 1e-12)
+    for rec in g["compare"]:
+        for p, ms in rec["details"].items():
+            names = list(ms)
+            rel, ok = ctx.compare([ms[m]["ref"] for m in names], [ms[m]["actual"] for m in names], rec["tolerance"])
+            for j, m in enumerate(names):
+                assert close(rel[j], ms[m]["rel_error"], 0.0) and bool(ok[j]) == ms[m]["passed"]
+    v = np.random.default_rng(3).normal(100.0, 1e-3, size=1_000_003)
+    out, exp = ctx.basic_stats(v), oracle.basic_stats(v)
+    assert close(out["mean"], exp["mean"], 1e-12) and close(out["std"], exp["std"], 1e-9)
+    out32 = ctx.basic_stats(v.astype(np.float32))
+    exp32 = oracle.basic_stats(v.astype(np.float32).astype(np.float64))
+    assert close(out32["mean"], exp32["mean"], 1e-12) and close(out32["std"], exp32["std"], 1e-9)
+
+
+def test_device_resident_async_and_profile(ctx, oracle):
+    from mcmc_ref_hip import synth
+    x = synth.c1_model(4, 2000, 6, seed=9)
+    t = ctx.upload(x, "pcn")
+    try:
+        ctx.profile(True)
+        ctx.profile_reset()
+        bufs = [ctx.enqueue(t) for _ in range(3)]
+        ctx.wait()
+        exp = oracle.summarize(x, "pcn")
+        for b in bufs:
+            check_summary(b.result(), exp, what="async")
+        prof = ctx.profile_get()
+        assert prof["k_tile_sort"]["launches"] == 3 and prof["k_diag"]["total_ms"] > 0
+        m, s = ctx.moments(t)
+        assert np.allclose(m, exp["mean"], rtol=1e-12) and np.allclose(s, exp["std"], rtol=1e-10)
+    finally:
+        ctx.profile(False)
+        t.free()
+
+
+def test_workspace_chunking_gives_identical_results(ctx):
+    from mcmc_ref_hip import synth
+    x = synth.c1_model(4, 3000, 9, seed=3)
+    full = ctx.summarize(x, "pcn")
+    ctx._check(ctx.lib.mcr_set_workspace_limit(ctx.handle, 2 << 20))   # forces ~3 params per chunk
+    try:
+        chunked = ctx.summarize(x, "pcn")
+    finally:
+        ctx._check(ctx.lib.mcr_set_workspace_limit(ctx.handle, 8 << 30))
+    for k in full:
+        assert np.array_equal(full[k], chunked[k], equal_nan=True), k
