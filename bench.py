@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- validated param-draws/s of the MI355X statistics hot path.
+
+One "step" = one full pass of the hot path (pooled mean/std, q5/q50/q95, rank-normalised split
+R-hat, ESS bulk, ESS tail, truncation lags) over one synthetic model resident in HBM.
+
+  python bench.py                                   # N=1, BASELINE config 1 (4 x 10000 x 100 f64)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU, weak scaling
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant
+kernel, HIP-event timed inside this process) and `cpu_baseline` (the C oracle on this host, 1 core).
+torch is imported only for N > 1 (rendezvous, barrier and the RCCL gather of the summaries).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+# Algorithmic (compulsory) HBM bytes per param-draw and launch of each kernel, f64 input
+# (DESIGN.md "Kernels and rooflines").  Intermediate traffic a kernel causes
+# beyond these is implementation overhead and shows up as a lower fraction.
+ALG_BYTES_PER_PD = {
+    "k_tile_sort": 8.0,     # the one compulsory read of the draw tensor
+    "k_merge": 8.0,         # (per pass) re-reads the keys it merges; idx payload is overhead
+    "k_fold_merge": 8.0,
+    "k_rank_z": 8.0,        # the 8-byte z it must produce per draw (keys are intermediates)
+    "k_diag": 16.0,         # reads z_bulk and z_tail once each
+    "k_ingest": 16.0,       # read + write of the layout change
+    "k_moments": 8.0,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--chains", type=int, default=4)
+    ap.add_argument("--draws", type=int, default=10000)
+    ap.add_argument("--params", type=int, default=100)
+    ap.add_argument("--layout", choices=["pcn", "cnp"], default="pcn",
+                    help="pcn = Arrow column layout [P][C][N]; cnp = Draws.to_numpy layout [C][N][P]")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--inflight", type=int, default=4, help="steps enqueued before a host wait (1..4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-validate", action="store_true")
+    return ap.parse_args()
+
+
+def validate(got: dict, exp: dict) -> tuple[bool, float]:
+    """Parity gate of the run that was timed: integers exact, floats <= 1e-6 relative."""
+    worst = 0.0
+    ok = np.array_equal(got["lag_bulk"], exp["lag_bulk"]) and np.array_equal(got["lag_tail"], exp["lag_tail"])
+    ok = ok and np.array_equal(got["q"], exp["q"]) and np.array_equal(got["median"], exp["median"])
+    for k in ("std", "rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
+        a, b = got[k], exp[k]
+        fin = np.isfinite(b)
+        ok = ok and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~fin & ~np.isnan(b)], b[~fin & ~np.isnan(b)])
+        if fin.any():
+            worst = max(worst, float(np.max(np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-300))))
+    err_mean = np.abs(got["mean"] - exp["mean"]) / (np.abs(exp["mean"]) + exp["std"])
+    worst = max(worst, float(np.max(err_mean)))
+    return bool(ok and worst <= 1e-6), worst
+
+
+def main():
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mcmc_ref_hip import _ffi, synth
+    ctx = _ffi.Context(local_rank)
+    C, N, P = a.chains, a.draws, a.params
+    dt = np.float64 if a.dtype == "f64" else np.float32
+    # independent models shard across ranks: rank r validates its own model (weak scaling)
+    x = synth.c1_model(C, N, P, seed=4711 + rank, dtype=dt)                 # [P][C][N]
+    host = x if a.layout == "pcn" else np.ascontiguousarray(np.transpose(x, (1, 2, 0)))
+    t = ctx.upload(host, a.layout)
+    inflight = max(1, min(a.inflight, _ffi.MCR_MAX_INFLIGHT))
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(steps):
+        last = None
+        for k in range(steps):
+            last = ctx.enqueue(t)
+            if (k + 1) % inflight == 0:
+                ctx.wait()
+        ctx.wait()
+        return last
+
+    run(a.warmup)
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    last = run(a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile(False)
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    got = last.result()
+
+    # final summary gather over RCCL: fixed-size per-parameter records to every rank
+    gathered_ok = True
+    if dist is not None:
+        rec = np.stack([got[k] for k in ("mean", "std", "rhat", "ess_bulk", "ess_tail")] +
+                       [got["lag_bulk"].astype(np.float64), got["lag_tail"].astype(np.float64)], axis=1)
+        mine = torch.from_numpy(rec).cuda()
+        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
+        dist.all_gather_into_tensor(allrec, mine)
+        gathered_ok = bool(torch.equal(allrec[rank], mine)) and allrec.shape[0] == world
+
+    valid, worst = True, 0.0
+    cpu = None
+    if not a.no_validate or not a.no_cpu_baseline:
+        from oracle import oracle as orc          # checker + cpu_baseline leg only
+        t1 = time.perf_counter()
+        exp = orc.summarize(host, a.layout)
+        cpu_s = time.perf_counter() - t1
+        if not a.no_validate:
+            valid, worst = validate(got, exp)
+        if rank == 0 and not a.no_cpu_baseline:
+            cpu = {"value": C * N * P / cpu_s, "unit": "param-draws/s", "cores": 1, "kind": "port",
+                   "sample": f"the same {C}x{N}x{P} {a.dtype} model, 1 pass of oracle/mcr_oracle.c "
+                             f"({cpu_s:.2f} s on {os.cpu_count()} available cores, 1 used)"}
+    if dist is not None:
+        flag = torch.tensor([1.0 if (valid and gathered_ok) else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        valid = bool(flag.item() > 0.5)
+
+    if rank == 0:
+        pd_step = C * N * P
+        es = 8 if a.dtype == "f64" else 4
+        kern = {}
+        dom, dom_ms = None, -1.0
+        for name, r in prof.items():
+            avg_ms = r["total_ms"] / max(r["launches"], 1)
+            alg = ALG_BYTES_PER_PD.get(name, 0.0) * (es / 8.0 if name in ("k_tile_sort", "k_moments") else 1.0)
+            kern[name] = {"launches_per_step": r["launches"] / a.steps, "avg_us": round(avg_ms * 1e3, 2),
+                          "alg_GBps": round(alg * pd_step / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None}
+            if r["total_ms"] > dom_ms and name in ALG_BYTES_PER_PD:
+                dom, dom_ms = name, r["total_ms"]
+        dom_avg_s = prof[dom]["total_ms"] / prof[dom]["launches"] * 1e-3
+        dom_alg = ALG_BYTES_PER_PD[dom] * (es / 8.0 if dom in ("k_tile_sort", "k_moments") else 1.0) * pd_step
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(f"{C}x{N}x{P}-{a.dtype}-{a.layout}", {}).get(dom)
+            except Exception:
+                traffic = None
+        achieved = dom_alg / dom_avg_s / 1e9
+        value = world * a.steps * pd_step / elapsed
+        out = {
+            "metric": "validated param-draws/sec", "value": value if valid else 0.0, "unit": "param-draws/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"single posteriordb-shaped model, {C}x{N}x{P} synthetic draws per GPU "
+                                   "(BASELINE config 1; AR(1) chains, ties and a shifted chain; SURVEY 8(d) C1)",
+                       "layout": a.layout, "statistics": "mean,std,q5,q50,q95,split_rhat,ess_bulk,ess_tail",
+                       "sharding": f"independent models, {world} rank(s), RCCL all_gather of summaries"},
+            "validated": valid, "max_rel_err": worst,
+            "pipeline_alg_GBps": value / world * es / 1e9,
+            "pipeline_frac_of_hbm": value / world * es / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_us": dom_avg_s * 1e6, "alg_bytes_per_launch": dom_alg},
+            "kernels": kern,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    t.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0 if valid else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
