@@ -132,15 +132,14 @@ def main():
         elapsed = float(tt.item())
     got = last.result()
 
-    # final summary gather over RCCL: fixed-size per-parameter records to every rank
+    # final summary gather over RCCL: fixed-size (128 B) per-parameter records to every rank
     gathered_ok = True
     if dist is not None:
-        rec = np.stack([got[k] for k in ("mean", "std", "rhat", "ess_bulk", "ess_tail")] +
-                       [got["lag_bulk"].astype(np.float64), got["lag_tail"].astype(np.float64)], axis=1)
-        mine = torch.from_numpy(rec).cuda()
-        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
-        dist.all_gather_into_tensor(allrec, mine)
-        gathered_ok = bool(torch.equal(allrec[rank], mine)) and allrec.shape[0] == world
+        from mcmc_ref_hip import shard
+        mine = shard.pack_records(got, rank, C, N)
+        allrec = shard.gather_records(mine, dist, device="cuda")
+        sel = allrec[allrec[:, shard.RECORD_FIELDS.index("model_idx")] == rank]
+        gathered_ok = allrec.shape[0] == world * P and np.array_equal(sel, mine, equal_nan=True)
 
     valid, worst = True, 0.0
     cpu = None

@@ -51,7 +51,9 @@ extern "C" {
 typedef struct mcr_ctx mcr_ctx;
 
 /* Per-parameter results, struct-of-arrays, caller allocated.  Every non-NULL array has P
- * entries, except q (P * n_q, row-major [p][k]) and q_lo (n_q).  NULL members are skipped.
+ * entries, except q (P * n_q, row-major [p][k]) and q_lo (n_q).  NULL members are skipped; when
+ * every diagnostics member (rhat* / ess_* / lag_*) is NULL the rank / fold / autocovariance
+ * kernels are not launched at all (Backend.stats-only call).
  *
  *  mean, std, q   Backend.stats(): pooled mean, population std (ddof=0), linear-interpolated
  *                 quantiles (src/mcmc_ref/backends.py:14-24, backends_arrow.py:36-51,

@@ -207,6 +207,7 @@ struct PipeIn {
     u32 *iA, *iB;
     i64* split;
     i64 ntiles;
+    bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
 };
 
 template <int NT, bool STAGE>
@@ -242,29 +243,31 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
     // 3. order statistics
     LAUNCH(ctx, K_ORDER_STATS, k_order_stats, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
            (const double*)kin, M, pc, a.q, a.d_res, a.split);
-    // 4. bulk ranks -> z
-    LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kin,
-           (const u32*)iin, M, a.zb, a.rank_b);
-    // 5. fold: one merge of the two monotone halves around the median
-    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3(nblk, py), dim3(kSortNT), kSortLds,
-           (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
-           (const i64*)a.split);
-    // 6. folded ranks -> z
-    LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kout,
-           (const u32*)iout, M, a.zt, a.rank_t);
-    // 7. R-hat + ESS
-    if (a.C >= 2) {
-        const size_t small256 = (size_t)(4 + 6 * a.C + 64 + 4 * 64 + 4) * 8;
-        const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
-        int rc;
-        if (a.n <= 2048) rc = launch_diag<256, true>(ctx, a, small256 + (size_t)a.n * 8);
-        else if ((size_t)a.n * 8 + small1024 <= 150 * 1024) rc = launch_diag<1024, true>(ctx, a, small1024 + (size_t)a.n * 8);
-        else rc = launch_diag<1024, false>(ctx, a, small1024);
-        if (rc) return rc;
+    if (a.do_diag) {
+        // 4. bulk ranks -> z
+        LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kin,
+               (const u32*)iin, M, a.zb, a.rank_b);
+        // 5. fold: one merge of the two monotone halves around the median
+        LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+               (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
+               (const i64*)a.split);
+        // 6. folded ranks -> z
+        LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kout,
+               (const u32*)iout, M, a.zt, a.rank_t);
+        // 7. R-hat + ESS
+        if (a.C >= 2) {
+            const size_t small256 = (size_t)(4 + 6 * a.C + 64 + 4 * 64 + 4) * 8;
+            const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
+            int rc;
+            if (a.n <= 2048) rc = launch_diag<256, true>(ctx, a, small256 + (size_t)a.n * 8);
+            else if ((size_t)a.n * 8 + small1024 <= 150 * 1024) rc = launch_diag<1024, true>(ctx, a, small1024 + (size_t)a.n * 8);
+            else rc = launch_diag<1024, false>(ctx, a, small1024);
+            if (rc) return rc;
+        }
     }
     // 8. finalize
     LAUNCH(ctx, K_FINALIZE, k_finalize, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0, (const double*)a.part,
-           (int)a.ntiles, M, a.X, pc, a.C, a.d_res);
+           (int)a.ntiles, M, a.X, pc, (a.do_diag ? a.C : 0), a.d_res);
     return MCR_OK;
 }
 
@@ -406,6 +409,8 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
             a.split = cv.take<i64>((size_t)pc);
             a.rank_b = a.rank_t = nullptr;
+            a.do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
+                        out->lag_bulk || out->lag_tail;
             if (ingest) {
                 double* X = cv.take<double>((size_t)pc * M);
                 rc = (dtype == MCR_F64) ? launch_ingest<double>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0)

@@ -123,7 +123,7 @@ SUMMARY_F64 = ("mean", "std", "median", "rhat", "rhat_bulk", "rhat_tail", "ess_b
 class SummaryBuffers:
     """Host arrays an mcr_summary points into (kept alive by this object)."""
 
-    def __init__(self, P: int, nq: int):
+    def __init__(self, P: int, nq: int, diagnostics: bool = True):
         self.P, self.nq = P, nq
         n = max(P, 1)
         self.arrays = {k: np.full(n, np.nan) for k in SUMMARY_F64}
@@ -133,6 +133,9 @@ class SummaryBuffers:
         self.arrays["q_lo"] = np.zeros(max(nq, 1), dtype=np.int64)
         kw = {k: _as_dp(self.arrays[k]) for k in SUMMARY_F64 + ("q",)}
         kw.update({k: _as_ip(self.arrays[k]) for k in ("lag_bulk", "lag_tail", "q_lo")})
+        if not diagnostics:     # NULL members: the library skips the diagnostics kernels
+            for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
+                kw[k] = None
         self.struct = Summary(**kw)
 
     def result(self) -> dict:
@@ -271,15 +274,19 @@ class Context:
         return qs
 
     def summarize(self, draws, layout: str = "pcn", min_chains: int = 4,
-                  quantiles=(0.05, 0.5, 0.95)) -> dict:
-        """All per-parameter statistics of a host array or a DeviceTensor (synchronous)."""
+                  quantiles=(0.05, 0.5, 0.95), diagnostics: bool = True) -> dict:
+        """All per-parameter statistics of a host array or a DeviceTensor (synchronous).
+
+        diagnostics=False: Backend.stats only (mean/std/quantiles/median); the rank, fold and
+        autocovariance kernels are not launched and the diagnostics come back as NaN.
+        """
         qs = self._quantiles(quantiles)
         if isinstance(draws, DeviceTensor):
             targs, ptr, fn = draws.targs, draws.buf.ptr, self.lib.mcr_summarize_dev
         else:
             targs, fn = tensor_args(draws, layout), self.lib.mcr_summarize
             ptr = draws.ctypes.data_as(C.c_void_p)
-        bufs = SummaryBuffers(targs[3], qs.size)
+        bufs = SummaryBuffers(targs[3], qs.size, diagnostics)
         self._check(fn(self.handle, ptr, *targs, int(min_chains), _as_dp(qs), qs.size, C.byref(bufs.struct)))
         return bufs.result()
 

@@ -1,0 +1,124 @@
+"""Backend registry with the MI355X "hip" backend.
+
+Mirrors src/mcmc_ref/backends.py:14-55 of the reference: the `Backend` protocol, the frozen
+`BackendSpec`, the `BACKENDS` dict and `get_backend(name)` with the same error text.  The only
+entry is "hip"; `register_into(registry)` adds it to the reference's own `BACKENDS` so that
+`reference.stats(model, backend="hip")` works unchanged.
+"""
+from __future__ import annotations
+
+from collections.abc import Callable, Iterable
+from dataclasses import dataclass
+from typing import Any, Protocol
+
+import numpy as np
+
+
+class Backend(Protocol):
+    name: str
+
+    def stats(
+        self,
+        table: Any,
+        params: Iterable[str],
+        quantiles: Iterable[float] = (0.05, 0.5, 0.95),
+        quantile_mode: str = "exact",
+    ) -> dict[str, dict[str, float]]:
+        """Compute per-parameter stats from an Arrow Table or batches."""
+
+
+@dataclass(frozen=True)
+class BackendSpec:
+    name: str
+    loader: Callable[[], Backend]
+
+
+def columns_to_matrix(table: Any, params: list[str]) -> np.ndarray:
+    """[P][M] float64 matrix of the requested columns (Arrow Table, reader, or mapping of arrays)."""
+    if hasattr(table, "read_all"):
+        table = table.read_all()
+    cols = []
+    for p in params:
+        if hasattr(table, "column"):
+            col = table.column(p)              # KeyError from pyarrow for unknown columns, as in the reference
+            arr = col.to_numpy(zero_copy_only=False) if hasattr(col, "to_numpy") else np.asarray(col)
+        else:
+            arr = np.asarray(table[p])
+        cols.append(np.asarray(arr, dtype=np.float64).reshape(-1))
+    if not cols:
+        return np.empty((0, 0), dtype=np.float64)
+    m = len(cols[0])
+    if any(len(c) != m for c in cols):
+        raise ValueError("all parameter columns must have the same length")
+    out = np.empty((len(cols), m), dtype=np.float64)
+    for i, c in enumerate(cols):
+        out[i] = c
+    return out
+
+
+class HipBackend:
+    """`Backend.stats` on the GPU: sort + order statistics + streaming moments kernels.
+
+    Same contract as ArrowBackend.stats / NumpyBackend.stats (src/mcmc_ref/backends_arrow.py:22-52,
+    backends_numpy.py:17-49): pooled mean, population std, linear-interpolated quantiles under the
+    keys f"q{int(q*100)}".  `quantile_mode` is accepted and ignored, as in the reference.
+    Null / NaN draws are rejected with ValueError instead of being skipped.
+    """
+
+    name = "hip"
+
+    def __init__(self, context=None) -> None:
+        from . import _ffi
+        try:
+            self._ctx = context or _ffi.default_context()
+        except _ffi.HipUnavailableError as exc:   # same shape as the reference's import guards
+            raise ImportError(f"libmcmcref_hip + an MI355X are required for the hip backend: {exc}") from exc
+
+    def stats(
+        self,
+        table,
+        params: Iterable[str],
+        quantiles: Iterable[float] = (0.05, 0.5, 0.95),
+        quantile_mode: str = "exact",
+    ) -> dict[str, dict[str, float]]:
+        from . import _ffi
+        params = list(params)
+        qs = list(quantiles)
+        x = columns_to_matrix(table, params)
+        if not params:
+            return {}
+        P, M = x.shape
+        if M == 0:
+            raise ValueError("cannot compute stats of empty columns")
+        try:
+            r = self._ctx.summarize(x.reshape(P, 1, M), "pcn", min_chains=1, quantiles=qs, diagnostics=False)
+        except _ffi.McrError as exc:
+            raise ValueError(exc.message) from exc
+        results: dict[str, dict[str, float]] = {}
+        for i, param in enumerate(params):
+            entry = {"mean": float(r["mean"][i]), "std": float(r["std"][i])}
+            for q, v in zip(qs, r["q"][i], strict=False):
+                entry[f"q{int(q * 100)}"] = float(v)
+            results[param] = entry
+        return results
+
+
+def _load_hip() -> Backend:
+    return HipBackend()
+
+
+BACKENDS: dict[str, BackendSpec] = {
+    "hip": BackendSpec(name="hip", loader=_load_hip),
+}
+
+
+def get_backend(name: str) -> Backend:
+    spec = BACKENDS.get(name)
+    if spec is None:
+        raise ValueError(f"Unknown backend: {name}")
+    return spec.loader()
+
+
+def register_into(registry: dict, spec_cls=BackendSpec) -> None:
+    """Add the "hip" entry to another registry (e.g. the reference's mcmc_ref.backends.BACKENDS)."""
+    registry["hip"] = spec_cls(name="hip", loader=_load_hip)

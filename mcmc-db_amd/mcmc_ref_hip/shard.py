@@ -1,0 +1,106 @@
+"""Multi-GPU sharding of independent models and the one collective of the path.
+
+Every statistic is per (model, parameter) (src/mcmc_ref/convert.py:140-147 is an independent
+loop), so models shard embarrassingly: one process per GPU, no data-path collective, and a single
+all_gather of fixed-size per-parameter summary records at the end (RCCL over xGMI when the
+process group backend is "nccl"; gloo on CPU for tests).  The gather is latency-bound: the whole
+packaged corpus is 460 records x 128 B = 59 KB.
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import numpy as np
+
+RECORD_FIELDS = ("mean", "std", "q5", "q50", "q95", "rhat_bulk", "rhat_tail", "rhat", "ess_bulk", "ess_tail",
+                 "lag_bulk", "lag_tail", "n_chains", "n_draws", "param_idx", "model_idx")
+RECORD_DOUBLES = len(RECORD_FIELDS)          # 16 doubles = 128 bytes
+
+
+def plan_shards(costs: Sequence[float], world: int) -> list[list[int]]:
+    """Greedy longest-processing-time assignment of models (by cost, e.g. C*N*P) to `world` ranks.
+
+    Deterministic: ties broken by model index, so every rank computes the same plan.
+    """
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    load = [0.0] * world
+    shards: list[list[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda k: (-float(costs[k]), k)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += float(costs[i])
+    for s in shards:
+        s.sort()
+    return shards
+
+
+def pack_records(summary: dict, model_idx: int, n_chains: int, n_draws: int) -> np.ndarray:
+    """[P][16] float64 records from a summarize() result computed with quantiles (0.05, 0.5, 0.95)."""
+    P = len(summary["mean"])
+    rec = np.empty((P, RECORD_DOUBLES), dtype=np.float64)
+    q = summary["q"]
+    cols = [summary["mean"], summary["std"], q[:, 0], q[:, 1], q[:, 2], summary["rhat_bulk"],
+            summary["rhat_tail"], summary["rhat"], summary["ess_bulk"], summary["ess_tail"],
+            summary["lag_bulk"].astype(np.float64), summary["lag_tail"].astype(np.float64),
+            np.full(P, float(n_chains)), np.full(P, float(n_draws)), np.arange(P, dtype=np.float64),
+            np.full(P, float(model_idx))]
+    for j, c in enumerate(cols):
+        rec[:, j] = c
+    return rec
+
+
+def gather_records(local: np.ndarray, dist=None, device=None) -> np.ndarray:
+    """all_gather of every rank's [n_r][16] records -> [sum n_r][16] on every rank, ordered by
+    (model_idx, param_idx).  `dist` is torch.distributed (initialised) or None for a single process."""
+    local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, RECORD_DOUBLES)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = local
+    else:
+        import torch
+        world = dist.get_world_size()
+        dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        nmax = n.clone()
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+        cap = int(nmax.item())
+        padded = torch.full((cap + 1, RECORD_DOUBLES), float("nan"), dtype=torch.float64, device=dev)
+        padded[0, 0] = float(local.shape[0])                      # row 0 carries the valid count
+        if local.shape[0]:
+            padded[1:1 + local.shape[0]] = torch.from_numpy(local).to(dev)
+        allp = torch.empty((world * (cap + 1), RECORD_DOUBLES), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allp, padded)      # concatenation along dim 0 (gloo and nccl)
+        allp = allp.cpu().numpy().reshape(world, cap + 1, RECORD_DOUBLES)
+        out = np.concatenate([allp[r, 1:1 + int(allp[r, 0, 0])] for r in range(world)], axis=0)
+    if out.shape[0]:
+        order = np.lexsort((out[:, RECORD_FIELDS.index("param_idx")], out[:, RECORD_FIELDS.index("model_idx")]))
+        out = out[order]
+    return out
+
+
+def summarize_models(ctx, models: Sequence[tuple[np.ndarray, str]], rank: int = 0, world: int = 1, dist=None,
+                     min_chains: int = 4) -> np.ndarray:
+    """Shard `models` ((array, layout) pairs) over ranks, summarise this rank's share on `ctx`
+    (up to MCR_MAX_INFLIGHT models in flight) and gather all records on every rank."""
+    from . import _ffi
+    costs = [float(np.prod(a.shape)) for a, _ in models]
+    mine = plan_shards(costs, world)[rank]
+    recs = []
+    pending = []
+
+    def drain():
+        ctx.wait()
+        for i, bufs, t, dims in pending:
+            recs.append(pack_records(bufs.result(), i, dims[0], dims[1]))
+            t.free()
+        pending.clear()
+
+    for i in mine:
+        arr, layout = models[i]
+        t = ctx.upload(np.ascontiguousarray(arr), layout)
+        pending.append((i, ctx.enqueue(t, min_chains=min_chains), t, t.shape_cnp))
+        if len(pending) == _ffi.MCR_MAX_INFLIGHT:
+            drain()
+    drain()
+    local = np.concatenate(recs, axis=0) if recs else np.empty((0, RECORD_DOUBLES))
+    return gather_records(local, dist)
