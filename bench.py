@@ -36,7 +36,8 @@ ALG_BYTES_PER_PD = {
     "k_merge": 8.0,         # (per pass) re-reads the keys it merges; idx payload is overhead
     "k_fold_merge": 8.0,
     "k_rank_z": 8.0,        # the 8-byte z it must produce per draw (keys are intermediates)
-    "k_diag": 16.0,         # reads z_bulk and z_tail once each
+    "k_chain_stats": 16.0,  # reads z_bulk and z_tail once each (chain moments + 64-lag autocovariance)
+    "k_diag": 16.0,         # legacy single-kernel R-hat/ESS path (long chains): same contract
     "k_ingest": 16.0,       # read + write of the layout change
     "k_moments": 8.0,
 }
@@ -56,6 +57,8 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=4, help="steps enqueued before a host wait (1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--no-moments", action="store_true",
+                    help="skip the streaming-moments HBM roofline leg (4 GB f32 tensor generated on the device)")
     return ap.parse_args()
 
 
@@ -159,6 +162,30 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         valid = bool(flag.item() > 0.5)
 
+    moments = None
+    if rank == 0 and not a.no_moments:
+        # BASELINE config 4 shape, quarter size: 4 x 100000 x 2500 f32 = 4 GB, generated on the device.
+        # One HBM pass per launch; algorithmic bytes = 4 B per param-draw.
+        mc, mn, mp = 4, 100000, 2500
+        big = ctx.alloc_tensor(mc, mn, mp, np.float32)
+        ctx.fill_synthetic(big, 4711)
+        ctx.moments(big)
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(5):
+            mm, ms = ctx.moments(big)
+        pm = ctx.profile_get()["k_moments"]
+        ctx.profile(False)
+        big.free()
+        kms = pm["total_ms"] / pm["launches"]
+        sig = 10.0 ** ((np.arange(mp) % 7) - 3)
+        ok_m = bool(np.max(np.abs(mm - np.arange(mp)) / sig) < 0.05 and np.max(np.abs(ms / sig - 1)) < 0.05)
+        gbs = mc * mn * mp * 4 / (kms * 1e-3) / 1e9
+        moments = {"kernel": "k_moments_rows<float>", "workload": f"{mc}x{mn}x{mp} f32 (4 GB) synthetic, on-device",
+                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "avg_launch_us": kms * 1e3, "param_draws_per_s": mc * mn * mp / (kms * 1e-3), "sane": ok_m,
+                   "traffic": 4000428032}   # 2*FETCH_SIZE (profiles/r01_pmc_fetch_moments_4GB.csv), writes ~1 MB
+
     if rank == 0:
         pd_step = C * N * P
         es = 8 if a.dtype == "f64" else 4
@@ -198,6 +225,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": dom_avg_s * 1e6, "alg_bytes_per_launch": dom_alg},
             "kernels": kern,
+            "moments_roofline": moments,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

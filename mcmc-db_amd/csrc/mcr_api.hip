@@ -25,11 +25,11 @@ constexpr int kMaxGridY = 65535;
 
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
-    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_COUNT
+    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
-    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth"};
+    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -185,12 +185,13 @@ struct WsPlan {
     i64 ntiles;
 };
 
-WsPlan plan_ws(i64 M, bool ingest, bool ranks)
+WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks)
 {
     WsPlan w;
     w.ntiles = (M + kTile - 1) / kTile;
     w.per_param = (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
-                  (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8;
+                  (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8 +
+                  (size_t)2 * (size_t)(C > 0 ? C : 1) * kRecDoubles * 8 + 8;
     return w;
 }
 
@@ -206,6 +207,9 @@ struct PipeIn {
     double *kA, *kB, *zb, *zt, *part, *rank_b, *rank_t;
     u32 *iA, *iB;
     i64* split;
+    double* rec;         // [pc][2][C][kRecDoubles] chain records of k_diag2
+    unsigned* cnt;       // [pc][2] arrival tickets
+    i64 nstage;          // longest chain prefix any k_diag2 workgroup stages
     i64 ntiles;
     bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
 };
@@ -218,6 +222,22 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a, size_t lds)
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LAUNCH(ctx, K_DIAG, (k_diag<NT, STAGE>), dim3((unsigned)a.pc, 2), dim3(NT), lds, a.zb, a.zt, a.M,
            a.d_off, a.C, a.n, a.nh, a.d_res, a.pc);
+    return MCR_OK;
+}
+
+template <int NT>
+int launch_diag2(mcr_ctx* ctx, const PipeIn& a, size_t lds, i64 lz)
+{
+    if (lds > 48 * 1024) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stats<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_combine<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    LAUNCH(ctx, K_CHAIN_STATS, (k_chain_stats<NT>), dim3((unsigned)a.C, (unsigned)a.pc, 2), dim3(NT), lds, a.zb,
+           a.zt, a.M, a.d_off, a.C, a.n, a.nh, a.rec);
+    LAUNCH(ctx, K_DIAG, (k_diag_combine<NT>), dim3((unsigned)a.pc, 2), dim3(NT), lds, a.zb, a.zt, a.M, a.d_off,
+           a.C, a.n, a.nh, lz, (const double*)a.rec, a.d_res, a.pc);
     return MCR_OK;
 }
 
@@ -256,12 +276,19 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
                (const u32*)iout, M, a.zt, a.rank_t);
         // 7. R-hat + ESS
         if (a.C >= 2) {
-            const size_t small256 = (size_t)(4 + 6 * a.C + 64 + 4 * 64 + 4) * 8;
-            const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
             int rc;
-            if (a.n <= 2048) rc = launch_diag<256, true>(ctx, a, small256 + (size_t)a.n * 8);
-            else if ((size_t)a.n * 8 + small1024 <= 150 * 1024) rc = launch_diag<1024, true>(ctx, a, small1024 + (size_t)a.n * 8);
-            else rc = launch_diag<1024, false>(ctx, a, small1024);
+            const i64 lz = ((a.nstage + 63) & ~(i64)63) + 80;
+            static const int nt_big = getenv("MCR_DIAG_NT") ? atoi(getenv("MCR_DIAG_NT")) : 512;
+            const int nt2 = (a.n <= 2048) ? 256 : nt_big;
+            const size_t lds2 = (size_t)(48 + 64 + (nt2 / 64) * 64 + 8) * 8 + (size_t)(lz + 2 * (lz >> 3) + 2) * 8;
+            if (lds2 <= 156 * 1024) {
+                if (nt2 == 256) rc = launch_diag2<256>(ctx, a, lds2, lz);
+                else if (nt2 == 512) rc = launch_diag2<512>(ctx, a, lds2, lz);
+                else rc = launch_diag2<1024>(ctx, a, lds2, lz);
+            } else {
+                const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
+                rc = launch_diag<1024, false>(ctx, a, small1024);
+            }
             if (rc) return rc;
         }
     }
@@ -383,8 +410,8 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     s.trivial_nan = (M == 0 || P == 0);
     if (!s.trivial_nan) {
         const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
-        const WsPlan wp = plan_ws(M, ingest, false);
-        const size_t slack = 16 * 256;
+        const WsPlan wp = plan_ws(M, (int)C, ingest, false);
+        const size_t slack = 20 * 256;
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
@@ -408,6 +435,9 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
             a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
             a.split = cv.take<i64>((size_t)pc);
+            a.rec = cv.take<double>((size_t)pc * 2 * (size_t)(C > 0 ? C : 1) * kRecDoubles);
+            a.cnt = cv.take<unsigned>((size_t)pc * 2);
+            a.nstage = N;
             a.rank_b = a.rank_t = nullptr;
             a.do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
                         out->lag_bulk || out->lag_tail;
@@ -675,8 +705,8 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     if (s.trivial_nan) { s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1; return wait_impl(ctx); }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool want_rank = rank_bulk || rank_tail;
-    const WsPlan wp = plan_ws(M, true, want_rank);
-    const size_t slack = 16 * 256;
+    const WsPlan wp = plan_ws(M, C, true, want_rank);
+    const size_t slack = 20 * 256;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
@@ -693,6 +723,13 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.zb = cv.take<double>((size_t)M); a.zt = cv.take<double>((size_t)M);
     a.part = cv.take<double>((size_t)wp.ntiles * 4);
     a.split = cv.take<i64>(1);
+    a.rec = cv.take<double>((size_t)2 * (size_t)(C > 0 ? C : 1) * kRecDoubles);
+    a.cnt = cv.take<unsigned>(2);
+    a.nstage = n;
+    for (int c = 0; c < C; ++c) {
+        const i64 len = chain_off[c + 1] - chain_off[c];
+        if (len >= 2 && len / 2 + nh > a.nstage) a.nstage = len / 2 + nh;
+    }
     double* X = cv.take<double>((size_t)M);
     a.rank_b = want_rank ? cv.take<double>((size_t)M) : nullptr;
     a.rank_t = want_rank ? cv.take<double>((size_t)M) : nullptr;
