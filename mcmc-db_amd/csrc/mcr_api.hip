@@ -25,11 +25,12 @@ constexpr int kMaxGridY = 65535;
 
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
-    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_COUNT
+    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
-    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats"};
+    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
+    "k_bucket_merge"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -183,13 +184,23 @@ struct Carve {
 struct WsPlan {
     size_t per_param;  // bytes per parameter (upper bound incl. alignment slack handled separately)
     i64 ntiles;
+    int bk_B = 0, bk_D = 0;  // bucket path (ntiles <= kMaxBucketTiles): #buckets, samples per bucket
 };
 
 WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks)
 {
     WsPlan w;
     w.ntiles = (M + kTile - 1) / kTile;
-    w.per_param = (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
+    if (w.ntiles <= kMaxBucketTiles) {
+        const int k = (int)w.ntiles;
+        const i64 last = M - (w.ntiles - 1) * kTile;
+        const i64 sf = (w.ntiles - 1) * 64 + last / 64;   // finite regular samples
+        w.bk_D = (4096 - 79 * k) / 64;                     // 64*D + 64*k + 15*k <= 4096
+        w.bk_B = (int)((sf + w.bk_D - 1) / w.bk_D);
+        if (w.bk_B < 1) w.bk_B = 1;
+    }
+    w.per_param = (size_t)w.ntiles * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.ntiles + 1) * 4 + 16 +
+                  (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
                   (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) * kRecDoubles * 8 + 8;
     return w;
@@ -210,6 +221,10 @@ struct PipeIn {
     double* rec;         // [pc][2][C][kRecDoubles] chain records of k_diag2
     unsigned* cnt;       // [pc][2] arrival tickets
     i64 nstage;          // longest chain prefix any k_diag2 workgroup stages
+    double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
+    u32* cut;            // [pc][B+1][ntiles]
+    u32* boff;           // [pc][B+1]
+    int bk_B = 0, bk_D = 0;
     i64 ntiles;
     bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
 };
@@ -246,27 +261,42 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
 {
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
-    // 1. tile sort (+ moment partials)
+    // 1. tile sort (+ moment partials, + regular samples for the bucket partition)
+    const bool bucket = a.bk_B > 0;
     LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<kSortNT, kSortVT>), dim3((unsigned)a.ntiles, py), dim3(kSortNT),
-           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles);
-    // 2. merge passes
+           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles, bucket ? a.samp : (double*)nullptr);
     double *kin = a.kA, *kout = a.kB;
     u32 *iin = a.iA, *iout = a.iB;
     const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
-    for (i64 R = kTile; R < M; R *= 2) {
-        LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
-               (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-               (const i64*)nullptr);
+    bool ranked = false;
+    if (bucket) {
+        // 2a. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
+        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(256), 0, (const double*)kin, (const double*)a.samp, M,
+               (int)a.ntiles, a.bk_B, a.bk_D, a.cut, a.boff);
+        LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3((unsigned)a.bk_B, py), dim3(256), kSortLds + 512,
+               (const double*)kin, (const u32*)iin, kout, iout, M, (int)a.ntiles, a.bk_B, (const u32*)a.cut,
+               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b);
         std::swap(kin, kout);
         std::swap(iin, iout);
+        ranked = true;
+    } else {
+        // 2b. long pooled arrays: pairwise merge-path passes
+        for (i64 R = kTile; R < M; R *= 2) {
+            LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+                   (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
+                   (const i64*)nullptr);
+            std::swap(kin, kout);
+            std::swap(iin, iout);
+        }
     }
     // 3. order statistics
     LAUNCH(ctx, K_ORDER_STATS, k_order_stats, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
            (const double*)kin, M, pc, a.q, a.d_res, a.split);
     if (a.do_diag) {
-        // 4. bulk ranks -> z
-        LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kin,
-               (const u32*)iin, M, a.zb, a.rank_b);
+        // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)
+        if (!ranked)
+            LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
+                   (const double*)kin, (const u32*)iin, M, a.zb, a.rank_b);
         // 5. fold: one merge of the two monotone halves around the median
         LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3(nblk, py), dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
@@ -411,7 +441,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     if (!s.trivial_nan) {
         const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
         const WsPlan wp = plan_ws(M, (int)C, ingest, false);
-        const size_t slack = 20 * 256;
+        const size_t slack = 24 * 256;
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
@@ -438,6 +468,10 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             a.rec = cv.take<double>((size_t)pc * 2 * (size_t)(C > 0 ? C : 1) * kRecDoubles);
             a.cnt = cv.take<unsigned>((size_t)pc * 2);
             a.nstage = N;
+            a.samp = cv.take<double>((size_t)pc * wp.ntiles * 64);
+            a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)wp.ntiles);
+            a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
+            a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
             a.rank_b = a.rank_t = nullptr;
             a.do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
                         out->lag_bulk || out->lag_tail;
@@ -706,7 +740,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool want_rank = rank_bulk || rank_tail;
     const WsPlan wp = plan_ws(M, C, true, want_rank);
-    const size_t slack = 20 * 256;
+    const size_t slack = 24 * 256;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
@@ -730,6 +764,10 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         const i64 len = chain_off[c + 1] - chain_off[c];
         if (len >= 2 && len / 2 + nh > a.nstage) a.nstage = len / 2 + nh;
     }
+    a.samp = cv.take<double>((size_t)wp.ntiles * 64);
+    a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)wp.ntiles);
+    a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));
+    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
     double* X = cv.take<double>((size_t)M);
     a.rank_b = want_rank ? cv.take<double>((size_t)M) : nullptr;
     a.rank_t = want_rank ? cv.take<double>((size_t)M) : nullptr;

@@ -239,7 +239,8 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
 template <int NT, int VT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, i64 M,
                                                   double* __restrict__ keys, u32* __restrict__ idx,
-                                                  double* __restrict__ part, int ntiles)
+                                                  double* __restrict__ part, int ntiles,
+                                                  double* __restrict__ samp)
 {
     constexpr int T = NT * VT;
     constexpr int TP = T + T / 16;
@@ -313,6 +314,11 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
     for (int e = tid; e < count; e += NT) {
         keys[p * M + base + e] = skey[pos16(e)];
         idx[p * M + base + e] = sidx[pos16(e)];
+    }
+    // regular samples (every 64th order statistic of the tile) for the exact bucket partition
+    if (samp != nullptr && tid < T / 64) {
+        const int e = 64 * tid + 63;
+        samp[(p * ntiles + tile) * (T / 64) + tid] = (e < count) ? skey[pos16(e)] : INFINITY;
     }
     s1 = block_sum<NT>(s1, red);
     s2 = block_sum<NT>(s2, red);
@@ -420,6 +426,224 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     for (int e = tid; e < total; e += NT) {
         kout[p * M + o0 + e] = skey[pos16(e)];
         iout[p * M + o0 + e] = sidx[pos16(e)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact k-way partition by regular sampling (k = #tiles <= 16).
+//
+// Every sorted tile contributes its 64th, 128th, ... order statistics.  In the strict total order
+// (value, tile, position) the sample of pooled sample-rank r has between 64(r+1) and 64(r+1)+64k
+// draws at or below it, so cutting at every D-th sample gives buckets of fewer than 64(D+k) draws:
+// with D = 64 - k - ceil(15k/64) a bucket, each of its <= k pieces padded to a multiple of 16,
+// always fits the 4096-slot LDS of k_bucket_merge -- a deterministic bound, no overflow path.
+// One workgroup per parameter writes cut[p][b][t] (start of bucket b inside tile t, b = 0..B) and
+// boff[p][b] (start of bucket b in the pooled order).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxBucketTiles = 16;
+
+__global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ keys,
+                                                   const double* __restrict__ samp, i64 M, int k, int B,
+                                                   int D, u32* __restrict__ cut, u32* __restrict__ boff)
+{
+    constexpr int T = 4096, SPT = 64;
+    __shared__ double sv[kMaxBucketTiles * SPT];
+    __shared__ double splv[64];
+    __shared__ int splt[64], splp[64];
+    __shared__ u32 scut[65 * kMaxBucketTiles];
+    const int tid = threadIdx.x;
+    const i64 p = blockIdx.x;
+    const double* kp = keys + p * M;
+    const int S = k * SPT;
+    for (int i = tid; i < S; i += 256) sv[i] = samp[p * S + i];
+    __syncthreads();
+    // pooled rank of every finite sample: own index + samples of the other tiles below it
+    for (int i = tid; i < S; i += 256) {
+        const double v = sv[i];
+        if (!(v < INFINITY)) continue;
+        const int t = i / SPT, j = i % SPT;
+        int r = j;
+        for (int t2 = 0; t2 < k; ++t2) {
+            if (t2 == t) continue;
+            const double* a = sv + t2 * SPT;
+            int lo = 0, hi = SPT;  // count of samples of tile t2 that sort before (v, t, j)
+            if (t2 < t) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
+            else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
+            r += lo;
+        }
+        if ((r + 1) % D == 0) {
+            const int b = (r + 1) / D;
+            if (b >= 1 && b < B) { splv[b] = v; splt[b] = t; splp[b] = 64 * j + 63; }
+        }
+    }
+    __syncthreads();
+    // cuts: position in tile t where bucket b starts
+    for (int q = tid; q < (B + 1) * k; q += 256) {
+        const int b = q / k, t = q % k;
+        const i64 tbase = (i64)t * T;
+        const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+        u32 c;
+        if (b == 0) c = 0;
+        else if (b == B) c = (u32)cnt;
+        else {
+            const double v = splv[b];
+            const int ts = splt[b];
+            if (t == ts) c = (u32)(splp[b] + 1);
+            else {
+                const double* a = kp + tbase;
+                int lo = 0, hi = cnt;
+                if (t < ts) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
+                else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
+                c = (u32)lo;
+            }
+        }
+        scut[q] = c;
+        cut[(p * (B + 1) + b) * k + t] = c;
+    }
+    __syncthreads();
+    for (int b = tid; b <= B; b += 256) {
+        u32 o = 0;
+        for (int t = 0; t < k; ++t) o += scut[b * k + t];
+        boff[p * (B + 1) + b] = o;
+    }
+}
+
+// Tie run of sorted LDS position i inside [0, total): returns [s, e) (gallop + bisect in LDS).
+__device__ __forceinline__ void lds_tie_run(const double* skey, int total, int i, int& s, int& e)
+{
+    const double v = skey[pos16(i)];
+    s = i; e = i + 1;
+    if (i > 0 && skey[pos16(i - 1)] == v) {
+        int step = 1, hi = i - 1, lo = hi - step;
+        while (lo >= 0 && skey[pos16(lo)] == v) { hi = lo; step <<= 1; lo = hi - step; }
+        if (lo < -1) lo = -1;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) hi = m; else lo = m; }
+        s = hi;
+    }
+    if (i + 1 < total && skey[pos16(i + 1)] == v) {
+        int step = 1, lo = i + 1, hi = lo + step;
+        while (hi < total && skey[pos16(hi)] == v) { lo = hi; step <<= 1; hi = lo + step; }
+        if (hi > total) hi = total;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) lo = m; else hi = m; }
+        e = lo + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bucket merge: one workgroup per (bucket, parameter) gathers its <= k sorted pieces (one per tile)
+// into LDS, each padded with +inf to a multiple of 16, merges them with ceil(log2 k) merge-path
+// rounds, writes the bucket to its place in the pooled ascending order (for the fold step and the
+// order statistics) and -- fused -- turns positions into tie-averaged ranks, z = Phi^-1((r-1/2)/M)
+// and scatters z to time order (src/mcmc_ref/diagnostics.py:101-133).  Tie runs that touch a bucket
+// edge are completed with lower/upper bounds over the k sorted tiles, which are complete in memory.
+// Replaces log2(k) global merge passes + k_rank_z of the first version.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
+                                                      double* __restrict__ kout, u32* __restrict__ iout, i64 M,
+                                                      int k, int B, const u32* __restrict__ cut,
+                                                      const u32* __restrict__ boff, double* __restrict__ z,
+                                                      double* __restrict__ rank_out)
+{
+    constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* skey = reinterpret_cast<double*>(smem);
+    u32* sidx = reinterpret_cast<u32*>(skey + TP);
+    int* sst = reinterpret_cast<int*>(sidx + TP);   // padded piece starts [k+1], then scratch
+    int* spl = sst + 40;                            // piece lengths [k]
+    int* sps = spl + 40;                            // piece source offsets in tile [k]
+    i64* sedge = reinterpret_cast<i64*>(sps + 40);  // [4] global run bounds of the edge values
+
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const i64 p = blockIdx.y;
+    const double* kp = kin + p * M;
+    const u32* ip = iin + p * M;
+    const u32* c0 = cut + (p * (B + 1) + b) * k;
+    const u32* c1 = c0 + k;
+    if (tid == 0) {
+        int acc = 0;
+        for (int t = 0; t < k; ++t) {
+            const int len = (int)(c1[t] - c0[t]);
+            sst[t] = acc; spl[t] = len; sps[t] = (int)c0[t];
+            acc += (len + 15) & ~15;
+        }
+        sst[k] = acc;
+    }
+    __syncthreads();
+    const int padded = sst[k];          // <= 4096 by construction of D
+    const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
+    const i64 obase = boff[p * (B + 1) + b];
+    // gather pieces (+inf pads)
+    for (int e = tid; e < padded; e += NT) {
+        int t = 0;
+        while (t + 1 < k && e >= sst[t + 1]) ++t;
+        const int o = e - sst[t];
+        double v = INFINITY; u32 id = 0xFFFFFFFFu;
+        if (o < spl[t]) { const i64 g = (i64)t * T + sps[t] + o; v = kp[g]; id = ip[g]; }
+        skey[pos16(e)] = v; sidx[pos16(e)] = id;
+    }
+    __syncthreads();
+    // merge rounds over adjacent runs (run boundaries = sst[] at stride 2^r)
+    const int chunk0 = tid * VT;
+    for (int w = 1; w < k; w <<= 1) {
+        double kk[VT]; int srcs[VT]; u32 ix[VT];
+        const bool active = chunk0 < padded;
+        if (active) {
+            int ra = 0;   // first piece of the pair that contains chunk0
+            while (ra + 2 * w < k && chunk0 >= sst[ra + 2 * w]) ra += 2 * w;
+            const int a0 = sst[ra];
+            const int a1 = sst[(ra + w < k) ? ra + w : k];
+            const int b1 = sst[(ra + 2 * w < k) ? ra + 2 * w : k];
+            const int na = a1 - a0, nb = b1 - a1, diag = chunk0 - a0;
+            auto A = [&](i64 i) { return skey[pos16(a0 + (int)i)]; };
+            auto Bf = [&](i64 j) { return skey[pos16(a1 + (int)j)]; };
+            const int ai = (int)merge_path(A, (i64)na, Bf, (i64)nb, (i64)diag);
+            serial_merge<VT>(skey, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
+#pragma unroll
+            for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < VT; ++i) { skey[pos16(chunk0 + i)] = kk[i]; sidx[pos16(chunk0 + i)] = ix[i]; }
+        }
+        __syncthreads();
+    }
+    // pooled ascending order out
+    for (int e = tid; e < total; e += NT) {
+        kout[p * M + obase + e] = skey[pos16(e)];
+        iout[p * M + obase + e] = sidx[pos16(e)];
+    }
+    if (z == nullptr || total == 0) return;
+    // global extent of the tie runs touching the bucket edges: bounds over the k sorted tiles
+    if (tid < 4) sedge[tid] = 0;
+    __syncthreads();
+    if (tid < 2 * k) {
+        const int t = tid % k, which = tid / k;           // 0: first value, 1: last value
+        const double v = which ? skey[pos16(total - 1)] : skey[pos16(0)];
+        const i64 tbase = (i64)t * T;
+        const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+        const double* a = kp + tbase;
+        int lo = 0, hi = cnt;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+        const int lb = lo;
+        hi = cnt;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sedge[2 * which]), (unsigned long long)lb);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sedge[2 * which + 1]), (unsigned long long)lo);
+    }
+    __syncthreads();
+    const double vfirst = skey[pos16(0)], vlast = skey[pos16(total - 1)];
+    for (int e = tid; e < total; e += NT) {
+        int s, en;
+        lds_tie_run(skey, total, e, s, en);
+        const double v = skey[pos16(e)];
+        i64 gs = obase + s, ge = obase + en;
+        if (v == vfirst) gs = sedge[0];
+        if (v == vlast) ge = sedge[3];
+        const double r = (double)(gs + 1 + ge) / 2.0;
+        const u32 t = sidx[pos16(e)];
+        z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
+        if (rank_out) rank_out[p * M + t] = r;
     }
 }
 
