@@ -19,7 +19,7 @@ using namespace mcr;
 namespace {
 
 constexpr int kSortNT = 256, kSortVT = 16, kTile = kSortNT * kSortVT;
-constexpr size_t kSortLds = (size_t)(kTile + kTile / 16) * 12 + 64;
+constexpr size_t kSortLds = (size_t)(kTile + kTile / 16) * 12 + 192;
 constexpr int kMaxChains = 256;
 constexpr int kMaxGridY = 65535;
 
@@ -273,9 +273,10 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         // 2a. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
         LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(256), 0, (const double*)kin, (const double*)a.samp, M,
                (int)a.ntiles, a.bk_B, a.bk_D, a.cut, a.boff);
-        LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3((unsigned)a.bk_B, py), dim3(256), kSortLds + 512,
+        const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
+        LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,
                (const double*)kin, (const u32*)iin, kout, iout, M, (int)a.ntiles, a.bk_B, (const u32*)a.cut,
-               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b);
+               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc);
         std::swap(kin, kout);
         std::swap(iin, iout);
         ranked = true;
@@ -284,7 +285,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         for (i64 R = kTile; R < M; R *= 2) {
             LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
                    (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-                   (const i64*)nullptr);
+                   (const i64*)nullptr, (double*)nullptr, (double*)nullptr);
             std::swap(kin, kout);
             std::swap(iin, iout);
         }
@@ -297,13 +298,11 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         if (!ranked)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
                    (const double*)kin, (const u32*)iin, M, a.zb, a.rank_b);
-        // 5. fold: one merge of the two monotone halves around the median
-        LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+        // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
+        LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3((unsigned)((pc + 7) / 8 * 8) * nblk),
+               dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
-               (const i64*)a.split);
-        // 6. folded ranks -> z
-        LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0, (const double*)kout,
-               (const u32*)iout, M, a.zt, a.rank_t);
+               (const i64*)a.split, a.zt, a.rank_t);
         // 7. R-hat + ESS
         if (a.C >= 2) {
             int rc;

@@ -101,6 +101,32 @@ __device__ __forceinline__ i64 merge_path(FA a, i64 na, FB b, i64 nb, i64 diag)
     return lo;
 }
 
+// The same split point found by a whole wave: 64 probes per step instead of one, so a search over
+// global memory costs ~log64(n) dependent round trips instead of log2(n).  All 64 lanes must call it
+// with identical arguments; every lane returns the result.
+template <class FA, class FB>
+__device__ __forceinline__ i64 merge_path_wave(FA a, i64 na, FB b, i64 nb, i64 diag)
+{
+    const int lane = threadIdx.x & 63;
+    i64 lo = diag > nb ? diag - nb : 0;
+    i64 hi = diag < na ? diag : na;
+    while (lo < hi) {
+        const i64 span = hi - lo;
+        const bool small = span <= 64;
+        const i64 mid = small ? lo + lane : lo + (span * (lane + 1)) / 65;
+        bool pred = false;
+        if (!small || lane < span) pred = !(b(diag - 1 - mid) < a(mid));   // monotone: true ... true false ... false
+        const int cnt = __popcll(__ballot(pred));
+        if (small) { lo += cnt; hi = lo; }
+        else {
+            const i64 nlo = (cnt == 0) ? lo : lo + (span * (i64)cnt) / 65 + 1;
+            const i64 nhi = (cnt == 64) ? hi : lo + (span * (i64)(cnt + 1)) / 65;
+            lo = nlo; hi = nhi;
+        }
+    }
+    return lo;
+}
+
 // LDS index padding: one pad slot per 16 elements, so that "thread t owns elements
 // [16t, 16t+16)" accesses (stride 17 doubles across lanes) are bank-conflict free.
 __device__ __forceinline__ int pos16(int e) { return e + (e >> 4); }

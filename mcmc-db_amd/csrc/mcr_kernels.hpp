@@ -30,6 +30,20 @@ struct QArgs {
     double g[32];
 };
 
+// XCD-aware block -> (parameter, block-within-parameter) map for kernels that scatter into one
+// parameter's z array.  Workgroups are dealt round-robin over the 8 XCDs (blocks L and L+8 share
+// an XCD, each XCD has its own L2), so parameter p runs all its nb blocks on XCD p % 8, back to
+// back: its 8-byte scattered z stores then merge into whole lines in ONE L2 instead of leaving
+// partial sectors in eight.  Launch with a 1-D grid of ceil(P/8)*8*nb blocks.  Speed only.
+__device__ __forceinline__ bool xcd_map(i64 P, int nb, i64& p, int& blk)
+{
+    const i64 L = blockIdx.x;
+    const i64 xcd = L & 7, j = L >> 3;
+    p = (j / nb) * 8 + xcd;
+    blk = (int)(j % nb);
+    return p < P;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Ingest: arbitrary element strides / f32 -> X[p][c*N + t] f64.
 // rows variant: lanes run along t (coalesced when stride_n == 1).
@@ -329,6 +343,81 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
     }
 }
 
+// Tie run of sorted LDS position i inside [0, total): returns [s, e) (gallop + bisect in LDS).
+__device__ __forceinline__ void lds_tie_run(const double* skey, int total, int i, int& s, int& e)
+{
+    const double v = skey[pos16(i)];
+    s = i; e = i + 1;
+    if (i > 0 && skey[pos16(i - 1)] == v) {
+        int step = 1, hi = i - 1, lo = hi - step;
+        while (lo >= 0 && skey[pos16(lo)] == v) { hi = lo; step <<= 1; lo = hi - step; }
+        if (lo < -1) lo = -1;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) hi = m; else lo = m; }
+        s = hi;
+    }
+    if (i + 1 < total && skey[pos16(i + 1)] == v) {
+        int step = 1, lo = i + 1, hi = lo + step;
+        while (hi < total && skey[pos16(hi)] == v) { lo = hi; step <<= 1; hi = lo + step; }
+        if (hi > total) hi = total;
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) lo = m; else hi = m; }
+        e = lo + 1;
+    }
+}
+
+// Tie runs of a sorted LDS array by scans instead of per-element searches (uniform cost however heavy
+// the ties): thread t owns positions [16t, 16t+16); rs[i] / re[i] = block-local [start, end) of the
+// run of equal keys containing position 16t+i.  `wsh` = 2 * NT/64 ints of LDS scratch.
+template <int NT, int VT>
+__device__ __forceinline__ void block_tie_runs(const double* skey, int total, int* wsh, int (&rs)[VT],
+                                               int (&re)[VT])
+{
+    constexpr int NW = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = tid * VT;
+    bool h[VT];
+    double prev = (base > 0 && base - 1 < total) ? skey[pos16(base - 1)] : 0.0;
+    int cur = -1, first = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int g = base + i;
+        const double kv = (g < total) ? skey[pos16(g)] : 0.0;
+        h[i] = (g == 0) || (g >= total) || (prev != kv);
+        if (h[i]) { cur = g; if (first == 0x7fffffff) first = g; }
+        rs[i] = cur;
+        prev = kv;
+    }
+    // exclusive max-scan of `cur` (last head at or before the end of my chunk) over threads
+    int incl = cur;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, kWave); if (lane >= o) incl = max(incl, v); }
+    // exclusive reverse min-scan of `first`
+    int rinc = first;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(rinc, o, kWave); if (lane + o < 64) rinc = min(rinc, v); }
+    __syncthreads();
+    if (lane == 63) wsh[w] = incl;
+    if (lane == 0) wsh[NW + w] = rinc;
+    __syncthreads();
+    int carryL = -1, carryR = total;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+        if (ww < w) carryL = max(carryL, wsh[ww]);
+        if (ww > w) carryR = min(carryR, wsh[NW + ww]);
+    }
+    const int exL = __shfl_up(incl, 1, kWave), exR = __shfl_down(rinc, 1, kWave);
+    if (lane > 0) carryL = max(carryL, exL);
+    if (lane < 63) carryR = min(carryR, exR);
+    if (carryR > total) carryR = total;
+    int nxt = carryR;
+#pragma unroll
+    for (int i = VT - 1; i >= 0; --i) {
+        re[i] = nxt;
+        if (h[i]) nxt = base + i;
+        if (rs[i] < 0) rs[i] = carryL;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Merge pass.  FOLD == false: merges pairs of sorted runs of length R (merge sort pass).
 // FOLD == true : produces the ascending order of |x - med| from the ascending order of x with a
@@ -340,7 +429,8 @@ template <int NT, int VT, bool FOLD>
 __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
                                               double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                               i64 R, const double* __restrict__ res, i64 P,
-                                              const i64* __restrict__ split)
+                                              const i64* __restrict__ split, double* __restrict__ z,
+                                              double* __restrict__ rank_out)
 {
     constexpr int OB = NT * VT;
     constexpr int TP = OB + OB / 16;
@@ -350,8 +440,12 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     i64* sh = reinterpret_cast<i64*>(sidx + TP);
 
     const int tid = threadIdx.x;
-    const i64 p = blockIdx.y;
-    const i64 o0 = (i64)blockIdx.x * OB;
+    i64 p = blockIdx.y;
+    int blk = blockIdx.x;
+    if (FOLD) {   // 1-D XCD-aware grid (the fused z scatter of one parameter stays in one L2)
+        if (!xcd_map(P, (int)((M + OB - 1) / OB), p, blk)) return;
+    }
+    const i64 o0 = (i64)blk * OB;
     if (o0 >= M) return;
     const double* kp = kin + p * M;
     const u32* ip = iin + p * M;
@@ -379,8 +473,8 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
 
     auto GA = [&](i64 i) -> double { return FOLD ? med - kp[abase - i] : kp[abase + i]; };
     auto GB = [&](i64 j) -> double { return FOLD ? kp[bbase + j] - med : kp[bbase + j]; };
-    if (tid == 0) sh[0] = merge_path(GA, na, GB, nb, d0);
-    if (tid == 64) sh[1] = merge_path(GA, na, GB, nb, d1);
+    if (tid < 64) { const i64 r0 = merge_path_wave(GA, na, GB, nb, d0); if (tid == 0) sh[0] = r0; }
+    else if (tid < 128) { const i64 r1 = merge_path_wave(GA, na, GB, nb, d1); if (tid == 64) sh[1] = r1; }
     __syncthreads();
     const i64 ai0 = sh[0], ai1 = sh[1];
     const i64 bi0 = d0 - ai0;
@@ -423,9 +517,62 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
         }
     }
     __syncthreads();
-    for (int e = tid; e < total; e += NT) {
-        kout[p * M + o0 + e] = skey[pos16(e)];
-        iout[p * M + o0 + e] = sidx[pos16(e)];
+    if (z == nullptr) {
+        for (int e = tid; e < total; e += NT) {
+            kout[p * M + o0 + e] = skey[pos16(e)];
+            iout[p * M + o0 + e] = sidx[pos16(e)];
+        }
+        return;
+    }
+    // Fused ranks -> z (src/mcmc_ref/diagnostics.py:113-133): the merged order never goes to memory.
+    // Tie runs touching the block edges are completed with lower/upper bounds over the two runs.
+    // Does the first / last tie run continue outside this block?  Look at the one element before
+    // and after the block in each run; only then pay for the bound searches (rare: heavy ties).
+    if (tid == 0) {
+        const i64 bi1 = d1 - ai1;
+        const double v0 = skey[pos16(0)], v1 = skey[pos16(total - 1)];
+        bool ext0 = false, ext1 = false;
+        if (ai0 > 0 && GA(ai0 - 1) == v0) ext0 = true;
+        if (bi0 > 0 && GB(bi0 - 1) == v0) ext0 = true;
+        if (ai1 < na && GA(ai1) == v1) ext1 = true;
+        if (bi1 < nb && GB(bi1) == v1) ext1 = true;
+        sh[2] = ext0; sh[3] = ext1;
+    }
+    __syncthreads();
+    const bool ext0 = sh[2] != 0, ext1 = sh[3] != 0;
+    __syncthreads();
+    if ((ext0 || ext1) && tid < 8) {
+        const int which = tid >> 2, side = (tid >> 1) & 1, upper = tid & 1;   // value, run, bound kind
+        const double v = which ? skey[pos16(total - 1)] : skey[pos16(0)];
+        const i64 len = side ? nb : na;
+        i64 lo = 0, hi = len;
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            const double x = side ? GB(mid) : GA(mid);
+            const bool right = upper ? !(v < x) : (x < v);
+            if (right) lo = mid + 1; else hi = mid;
+        }
+        sh[2 + tid] = lo;
+    }
+    __syncthreads();
+    const double vfirst = skey[pos16(0)], vlast = skey[pos16(total - 1)];
+    const i64 gfirst = sh[2 + 0] + sh[2 + 2];   // lower bounds (both runs) of the first value
+    const i64 glast = sh[2 + 5] + sh[2 + 7];    // upper bounds (both runs) of the last value
+    int rs[VT], re[VT];
+    block_tie_runs<NT, VT>(skey, total, reinterpret_cast<int*>(sh + 12), rs, re);
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int e = tid * VT + i;
+        if (e < total) {
+            const double v = skey[pos16(e)];
+            i64 gs = d0 + rs[i], ge = d0 + re[i];
+            if (ext0 && v == vfirst) gs = gfirst;
+            if (ext1 && v == vlast) ge = glast;
+            const double r = (double)(gs + 1 + ge) / 2.0;
+            const u32 t = sidx[pos16(e)];
+            z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
+            if (rank_out) rank_out[p * M + t] = r;
+        }
     }
 }
 
@@ -508,27 +655,6 @@ __global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ ke
     }
 }
 
-// Tie run of sorted LDS position i inside [0, total): returns [s, e) (gallop + bisect in LDS).
-__device__ __forceinline__ void lds_tie_run(const double* skey, int total, int i, int& s, int& e)
-{
-    const double v = skey[pos16(i)];
-    s = i; e = i + 1;
-    if (i > 0 && skey[pos16(i - 1)] == v) {
-        int step = 1, hi = i - 1, lo = hi - step;
-        while (lo >= 0 && skey[pos16(lo)] == v) { hi = lo; step <<= 1; lo = hi - step; }
-        if (lo < -1) lo = -1;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) hi = m; else lo = m; }
-        s = hi;
-    }
-    if (i + 1 < total && skey[pos16(i + 1)] == v) {
-        int step = 1, lo = i + 1, hi = lo + step;
-        while (hi < total && skey[pos16(hi)] == v) { lo = hi; step <<= 1; hi = lo + step; }
-        if (hi > total) hi = total;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) lo = m; else hi = m; }
-        e = lo + 1;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Bucket merge: one workgroup per (bucket, parameter) gathers its <= k sorted pieces (one per tile)
 // into LDS, each padded with +inf to a multiple of 16, merges them with ceil(log2 k) merge-path
@@ -542,7 +668,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
                                                       double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                                       int k, int B, const u32* __restrict__ cut,
                                                       const u32* __restrict__ boff, double* __restrict__ z,
-                                                      double* __restrict__ rank_out)
+                                                      double* __restrict__ rank_out, i64 P)
 {
     constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -553,8 +679,10 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     int* sps = spl + 40;                            // piece source offsets in tile [k]
     i64* sedge = reinterpret_cast<i64*>(sps + 40);  // [4] global run bounds of the edge values
 
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const i64 p = blockIdx.y;
+    const int tid = threadIdx.x;
+    i64 p;
+    int b;
+    if (!xcd_map(P, B, p, b)) return;
     const double* kp = kin + p * M;
     const u32* ip = iin + p * M;
     const u32* c0 = cut + (p * (B + 1) + b) * k;
@@ -614,10 +742,24 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
         iout[p * M + obase + e] = sidx[pos16(e)];
     }
     if (z == nullptr || total == 0) return;
-    // global extent of the tie runs touching the bucket edges: bounds over the k sorted tiles
+    // Do the first / last tie runs continue in a neighbouring bucket?  Look at the element just
+    // before / after this bucket's piece in every tile; only then pay for the bound searches.
     if (tid < 4) sedge[tid] = 0;
+    if (tid < 64) {
+        bool e0 = false, e1 = false;
+        if (tid < k) {
+            const i64 tbase = (i64)tid * T;
+            const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+            const int lo = sps[tid], hi = sps[tid] + spl[tid];
+            if (lo > 0) e0 = (kp[tbase + lo - 1] == skey[pos16(0)]);
+            if (hi < cnt) e1 = (kp[tbase + hi] == skey[pos16(total - 1)]);
+        }
+        const bool a0 = __ballot(e0) != 0, a1 = __ballot(e1) != 0;
+        if (tid == 0) { sst[36] = a0; sst[37] = a1; }
+    }
     __syncthreads();
-    if (tid < 2 * k) {
+    const bool ext0 = sst[36] != 0, ext1 = sst[37] != 0;
+    if ((ext0 || ext1) && tid < 2 * k) {
         const int t = tid % k, which = tid / k;           // 0: first value, 1: last value
         const double v = which ? skey[pos16(total - 1)] : skey[pos16(0)];
         const i64 tbase = (i64)t * T;
@@ -633,17 +775,21 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     }
     __syncthreads();
     const double vfirst = skey[pos16(0)], vlast = skey[pos16(total - 1)];
-    for (int e = tid; e < total; e += NT) {
-        int s, en;
-        lds_tie_run(skey, total, e, s, en);
-        const double v = skey[pos16(e)];
-        i64 gs = obase + s, ge = obase + en;
-        if (v == vfirst) gs = sedge[0];
-        if (v == vlast) ge = sedge[3];
-        const double r = (double)(gs + 1 + ge) / 2.0;
-        const u32 t = sidx[pos16(e)];
-        z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
-        if (rank_out) rank_out[p * M + t] = r;
+    int rs[VT], re[VT];
+    block_tie_runs<NT, VT>(skey, total, sst + 24, rs, re);
+#pragma unroll
+    for (int i = 0; i < VT; ++i) {
+        const int e = tid * VT + i;
+        if (e < total) {
+            const double v = skey[pos16(e)];
+            i64 gs = obase + rs[i], ge = obase + re[i];
+            if (ext0 && v == vfirst) gs = sedge[0];
+            if (ext1 && v == vlast) ge = sedge[3];
+            const double r = (double)(gs + 1 + ge) / 2.0;
+            const u32 t = sidx[pos16(e)];
+            z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
+            if (rank_out) rank_out[p * M + t] = r;
+        }
     }
 }
 
