@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "mcr_kernels.hpp"
+#include "mcr_diag.hpp"
 
 using namespace mcr;
 
@@ -25,12 +26,13 @@ constexpr int kMaxGridY = 65535;
 
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
-    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_COUNT
+    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
+    K_DIAG2, K_ACOV_SEG, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
-    "k_bucket_merge"};
+    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -187,7 +189,7 @@ struct WsPlan {
     int bk_B = 0, bk_D = 0;  // bucket path (ntiles <= kMaxBucketTiles): #buckets, samples per bucket
 };
 
-WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks)
+WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
 {
     WsPlan w;
     w.ntiles = (M + kTile - 1) / kTile;
@@ -202,7 +204,9 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks)
     w.per_param = (size_t)w.ntiles * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.ntiles + 1) * 4 + 16 +
                   (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
                   (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8 +
-                  (size_t)2 * (size_t)(C > 0 ? C : 1) * kRecDoubles * 8 + 8;
+                  (size_t)2 * (size_t)(C > 0 ? C : 1) *
+                      ((size_t)((nstage + kSeg - 1) / kSeg + 1) * (kSegRec + 64 * kMoreBlocks) + kChState) * 8 +
+                  8 + 64;
     return w;
 }
 
@@ -218,9 +222,12 @@ struct PipeIn {
     double *kA, *kB, *zb, *zt, *part, *rank_b, *rank_t;
     u32 *iA, *iB;
     i64* split;
-    double* rec;         // [pc][2][C][kRecDoubles] chain records of k_diag2
-    unsigned* cnt;       // [pc][2] arrival tickets
-    i64 nstage;          // longest chain prefix any k_diag2 workgroup stages
+    double* rec;         // [pc][2][C][nseg][kSegRec] first-pass segment records
+    unsigned* more;      // [pc][2] continuation flags
+    double* state;       // [pc][2][4] rho scan state
+    double* chstate;     // [pc][2][C][kChState]
+    double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products 64..511
+    i64 nstage;          // longest chain prefix the segment grid has to cover
     double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
     u32* cut;            // [pc][B+1][ntiles]
     u32* boff;           // [pc][B+1]
@@ -229,30 +236,21 @@ struct PipeIn {
     bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
 };
 
-template <int NT, bool STAGE>
-int launch_diag(mcr_ctx* ctx, const PipeIn& a, size_t lds)
+// Split R-hat + ESS: segment products, combine, flagged continuation (mcr_diag.hpp).
+int launch_diag(mcr_ctx* ctx, const PipeIn& a)
 {
-    if (lds > 48 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<NT, STAGE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LAUNCH(ctx, K_DIAG, (k_diag<NT, STAGE>), dim3((unsigned)a.pc, 2), dim3(NT), lds, a.zb, a.zt, a.M,
-           a.d_off, a.C, a.n, a.nh, a.d_res, a.pc);
-    return MCR_OK;
-}
-
-template <int NT>
-int launch_diag2(mcr_ctx* ctx, const PipeIn& a, size_t lds, i64 lz)
-{
-    if (lds > 48 * 1024) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_stats<NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag_combine<NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    LAUNCH(ctx, K_CHAIN_STATS, (k_chain_stats<NT>), dim3((unsigned)a.C, (unsigned)a.pc, 2), dim3(NT), lds, a.zb,
-           a.zt, a.M, a.d_off, a.C, a.n, a.nh, a.rec);
-    LAUNCH(ctx, K_DIAG, (k_diag_combine<NT>), dim3((unsigned)a.pc, 2), dim3(NT), lds, a.zb, a.zt, a.M, a.d_off,
-           a.C, a.n, a.nh, lz, (const double*)a.rec, a.d_res, a.pc);
+    const int nseg = (int)((a.nstage + kSeg - 1) / kSeg);
+    const unsigned pk = (unsigned)(2 * a.pc);
+    LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<256, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0, a.zb,
+           a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, a.zb, a.zt, a.M,
+           a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate);
+    // continuation for pairs whose first negative rho lies beyond lag 63 (others exit at once)
+    LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<256, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0, a.zb,
+           a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+    LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(256), (size_t)2 * a.C * 8, a.zb, a.zt, a.M, a.d_off, a.C,
+           a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, (const double*)a.state,
+           (const double*)a.chstate, a.d_res, a.pc);
     return MCR_OK;
 }
 
@@ -305,19 +303,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
                (const i64*)a.split, a.zt, a.rank_t);
         // 7. R-hat + ESS
         if (a.C >= 2) {
-            int rc;
-            const i64 lz = ((a.nstage + 63) & ~(i64)63) + 80;
-            static const int nt_big = getenv("MCR_DIAG_NT") ? atoi(getenv("MCR_DIAG_NT")) : 512;
-            const int nt2 = (a.n <= 2048) ? 256 : nt_big;
-            const size_t lds2 = (size_t)(48 + 64 + (nt2 / 64) * 64 + 8) * 8 + (size_t)(lz + 2 * (lz >> 3) + 2) * 8;
-            if (lds2 <= 156 * 1024) {
-                if (nt2 == 256) rc = launch_diag2<256>(ctx, a, lds2, lz);
-                else if (nt2 == 512) rc = launch_diag2<512>(ctx, a, lds2, lz);
-                else rc = launch_diag2<1024>(ctx, a, lds2, lz);
-            } else {
-                const size_t small1024 = (size_t)(16 + 6 * a.C + 64 + 16 * 64 + 4) * 8;
-                rc = launch_diag<1024, false>(ctx, a, small1024);
-            }
+            const int rc = launch_diag(ctx, a);
             if (rc) return rc;
         }
     }
@@ -439,13 +425,13 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     s.trivial_nan = (M == 0 || P == 0);
     if (!s.trivial_nan) {
         const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
-        const WsPlan wp = plan_ws(M, (int)C, ingest, false);
-        const size_t slack = 24 * 256;
+        const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
+        const size_t slack = 32 * 256;
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
         if (pcmax > P) pcmax = P;
-        if (pcmax > kMaxGridY) pcmax = kMaxGridY;
+        if (pcmax > kMaxGridY / 2) pcmax = kMaxGridY / 2;   // k_acov_seg uses grid.z = 2 * pc
         rc = ensure_ws(ctx, (size_t)pcmax * wp.per_param + slack);
         if (rc) return rc;
         const int R = res_fields(nq);
@@ -464,9 +450,15 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
             a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
             a.split = cv.take<i64>((size_t)pc);
-            a.rec = cv.take<double>((size_t)pc * 2 * (size_t)(C > 0 ? C : 1) * kRecDoubles);
-            a.cnt = cv.take<unsigned>((size_t)pc * 2);
-            a.nstage = N;
+            {
+                const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((N + kSeg - 1) / kSeg + 1);
+                a.rec = cv.take<double>((size_t)pc * 2 * cc * ns * kSegRec);
+                a.rec2 = cv.take<double>((size_t)pc * 2 * cc * ns * 64 * kMoreBlocks);
+                a.chstate = cv.take<double>((size_t)pc * 2 * cc * kChState);
+                a.more = cv.take<unsigned>((size_t)pc * 2);
+                a.state = cv.take<double>((size_t)pc * 2 * 4);
+            }
+            a.nstage = N > 0 ? N : 1;
             a.samp = cv.take<double>((size_t)pc * wp.ntiles * 64);
             a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)wp.ntiles);
             a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
@@ -738,8 +730,13 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     if (s.trivial_nan) { s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1; return wait_impl(ctx); }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool want_rank = rank_bulk || rank_tail;
-    const WsPlan wp = plan_ws(M, C, true, want_rank);
-    const size_t slack = 24 * 256;
+    i64 nstage = n > 0 ? n : 1;
+    for (int c = 0; c < C; ++c) {
+        const i64 len = chain_off[c + 1] - chain_off[c];
+        if (len >= 2 && len / 2 + nh > nstage) nstage = len / 2 + nh;
+    }
+    const WsPlan wp = plan_ws(M, C, true, want_rank, nstage);
+    const size_t slack = 32 * 256;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
@@ -756,13 +753,15 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.zb = cv.take<double>((size_t)M); a.zt = cv.take<double>((size_t)M);
     a.part = cv.take<double>((size_t)wp.ntiles * 4);
     a.split = cv.take<i64>(1);
-    a.rec = cv.take<double>((size_t)2 * (size_t)(C > 0 ? C : 1) * kRecDoubles);
-    a.cnt = cv.take<unsigned>(2);
-    a.nstage = n;
-    for (int c = 0; c < C; ++c) {
-        const i64 len = chain_off[c + 1] - chain_off[c];
-        if (len >= 2 && len / 2 + nh > a.nstage) a.nstage = len / 2 + nh;
+    {
+        const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((nstage + kSeg - 1) / kSeg + 1);
+        a.rec = cv.take<double>((size_t)2 * cc * ns * kSegRec);
+        a.rec2 = cv.take<double>((size_t)2 * cc * ns * 64 * kMoreBlocks);
+        a.chstate = cv.take<double>((size_t)2 * cc * kChState);
+        a.more = cv.take<unsigned>(2);
+        a.state = cv.take<double>(8);
     }
+    a.nstage = nstage;
     a.samp = cv.take<double>((size_t)wp.ntiles * 64);
     a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)wp.ntiles);
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));

@@ -1,0 +1,451 @@
+// mcr_diag.hpp -- split R-hat and ESS from the rank-normalised draws z (time order).
+//
+// Reference: src/mcmc_ref/diagnostics.py:76-85 (_split_chains), :136-151 (_rhat), :154-193 (_ess,
+// _autocorr: UNSPLIT chains, per-chain mean of the full chain, (n - lag) normaliser, stop at the
+// first negative rho), :196-201 (_variance, ddof=1).
+//
+// Structure (all fp64 VALU; LDS only as a staging buffer):
+//   k_acov_seg      grid (segment, chain, parameter x kind).  A workgroup stages 2048 draws of one
+//                   chain (+ a 72-draw halo) ONCE in LDS (swizzled so that 16-byte reads at 64-byte
+//                   lane spacing hit distinct banks) and forms the raw lag products
+//                   P_l = sum_i z_i z_{i+l} for 64 lags with an 8 (i) x 8 (lag) register tile per
+//                   lane: 12 ds_read_b128 feed 64 FMAs, so the loop runs at the fp64 FMA rate.
+//                   Products are taken on the raw z (no mean yet): the mean correction
+//                       sum (z_i - m)(z_{i+l} - m) = P_l - m (2S - head_l - tail_l) + (n - l) m^2
+//                   is applied in the combine step, which makes the pass single-sweep, independent
+//                   of chain length (any n), and fine-grained enough to fill 256 CUs.
+//                   Lag 0 gives sum z^2, so variances cost nothing extra.
+//   k_diag_combine  one wave per (parameter, kind): per-chain means / variances, split R-hat,
+//                   var_hat, and the rho terms of lags 1..63 accumulated left to right like the
+//                   reference's loop.  Pairs whose first negative rho lies beyond lag 63 are flagged.
+//   k_acov_seg      again, for flagged pairs only (others exit at once): lags 64..255.
+//   k_diag_combine2 continues the scan; beyond lag 255 (very sticky chains) it finishes with a
+//                   direct deviation-product loop over L2.
+// A chain that is exactly constant (min == max) contributes exactly zero deviations, as in the
+// reference when its mean is exact; this keeps the W == 0 branches of _rhat / _ess exact.
+#pragma once
+#include "mcr_device.hpp"
+
+namespace mcr {
+
+constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup
+constexpr int kSegRec = 80;     // doubles per first-pass record: 64 lag products + 7 scalars
+constexpr int kMoreBlocks = 3;  // continuation pass covers lags 64 .. 64 + 64*3 - 1 = 255
+enum SegField { SG_S = 64, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
+
+__device__ __forceinline__ i64 pos8(i64 j) { return j + ((j >> 3) << 1); }
+
+// Three deterministic block sums with one barrier pair.  `red` holds 3 * NT/64 doubles.
+template <int NT>
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red)
+{
+    constexpr int NW = NT / kWave;
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[w] = a; red[NW + w] = b; red[2 * NW + w] = c;
+    }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0, rc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { ra += red[w]; rb += red[NW + w]; rc += red[2 * NW + w]; }
+    a = ra; b = rb; c = rc;
+    __syncthreads();
+}
+
+// One 64-lag block of raw products for the staged segment.  A: swizzled segment (kSeg + 16),
+// B: swizzled window starting `lag base` draws later (kSeg + 80); both zero padded.  Result in
+// tot[0..63].  All NT threads must call it.
+template <int NT>
+__device__ __forceinline__ void seg_products(const double* __restrict__ A, const double* __restrict__ B,
+                                             int seglen, double* tot, double* wred)
+{
+    constexpr int NW = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane & 7, ph = lane >> 3;
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    const int nit = (seglen + 63) >> 6;
+    for (int it = w; it < nit; it += NW) {
+        const int i0 = (it << 6) + (ph << 3);
+        const int s = i0 + (g << 3);
+        const double2* pa = reinterpret_cast<const double2*>(A + 10 * (i0 >> 3));
+        const double2* pb = reinterpret_cast<const double2*>(B + 10 * (s >> 3));
+        double a[8], b[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 v = pa[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 v = pb[j]; b[2 * j] = v.x; b[2 * j + 1] = v.y; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double2 v = pb[5 + j]; b[8 + 2 * j] = v.x; b[9 + 2 * j] = v.y; }
+#pragma unroll
+        for (int li = 0; li < 8; ++li)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[li] = fma(a[k], b[k + li], acc[li]);
+    }
+#pragma unroll
+    for (int li = 0; li < 8; ++li) {
+        acc[li] += __shfl_xor(acc[li], 8, kWave);
+        acc[li] += __shfl_xor(acc[li], 16, kWave);
+        acc[li] += __shfl_xor(acc[li], 32, kWave);
+    }
+    __syncthreads();  // wred / tot may still be in use
+    if (ph == 0) {
+#pragma unroll
+        for (int li = 0; li < 8; ++li) wred[w * 64 + (g << 3) + li] = acc[li];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+}
+
+// FIRST == true : lags 0..63 + the segment's sums (record of kSegRec doubles), every pair.
+// FIRST == false: lags 64..64+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
+// grid (nseg, C, 2 * P); blockIdx.z = 2 * p + kind.
+template <int NT, bool FIRST>
+__global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, const double* __restrict__ zt,
+                                                 i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
+                                                 int nseg, const unsigned* __restrict__ more,
+                                                 double* __restrict__ rec)
+{
+    constexpr int NW = NT / kWave;
+    constexpr int LA = (kSeg + 16) / 8 * 10, LB = (kSeg + 80) / 8 * 10;
+    __shared__ __attribute__((aligned(16))) double sB[LB];
+    __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
+    __shared__ double tot[64];
+    __shared__ double wred[NW * 64];
+    __shared__ double red[3 * NW];
+
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x, c = blockIdx.y;
+    const i64 pk = blockIdx.z, p = pk >> 1;
+    const int kind = (int)(pk & 1);
+    if (!FIRST && more[pk] == 0u) return;
+    const double* zc = (kind ? zt : zb) + p * M + off[c];
+    const i64 nc = off[c + 1] - off[c], hc = nc / 2;
+    const i64 hspan = (hc > 0) ? hc + nh : 0;
+    const i64 nload = (n > hspan) ? n : hspan;          // <= nc
+    const i64 s0 = (i64)seg * kSeg;
+    const int seglen = (int)((n - s0 < 0) ? 0 : ((n - s0 < (i64)kSeg) ? n - s0 : (i64)kSeg));
+
+    if (FIRST) {
+        // ---- stage (9 loads in flight per lane) + segment sums ----
+        double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0, dummy = 0.0;
+        double vmin = INFINITY, vmax = -INFINITY;
+        double v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const i64 g = s0 + u * NT + tid;
+            v[u] = (u * NT + tid < kSeg + 80 && g < nload) ? zc[g] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int j = u * NT + tid;
+            const i64 g = s0 + j;
+            if (j < kSeg + 80) {
+                if (j < kSeg && g < nload) {       // this workgroup owns draw g
+                    if (g < n) { S += v[u]; vmin = fmin(vmin, v[u]); vmax = fmax(vmax, v[u]); }
+                    if (hc > 0) {
+                        if (g < nh) { S0 += v[u]; Q0 = fma(v[u], v[u], Q0); }
+                        if (g >= hc && g < hc + nh) { S1 += v[u]; Q1 = fma(v[u], v[u], Q1); }
+                    }
+                }
+                sB[pos8(j)] = (g < n) ? v[u] : 0.0;
+            }
+        }
+        block_sum3<NT>(S, S0, Q0, red);
+        block_sum3<NT>(S1, Q1, dummy, red);
+        for (int o = 32; o > 0; o >>= 1) {
+            vmin = fmin(vmin, __shfl_xor(vmin, o, kWave));
+            vmax = fmax(vmax, __shfl_xor(vmax, o, kWave));
+        }
+        if ((tid & 63) == 0) { wred[tid >> 6] = vmin; wred[NW + (tid >> 6)] = vmax; }
+        __syncthreads();
+        double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) { vmin = fmin(vmin, wred[w]); vmax = fmax(vmax, wred[NW + w]); }
+            r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
+            r[SG_MIN] = vmin; r[SG_MAX] = vmax;
+        }
+        seg_products<NT>(sB, sB, seglen, tot, wred);
+        if (tid < 64) r[tid] = tot[tid];
+    } else {
+        if (seglen == 0) {   // nothing of [0, n) in this segment: zero record
+            double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
+            for (int j = tid; j < 64 * kMoreBlocks; j += NT) r[j] = 0.0;
+            return;
+        }
+        for (int j = tid; j < kSeg + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+        double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
+        for (int blk = 0; blk < kMoreBlocks; ++blk) {
+            const i64 lb = 64 + 64 * blk;
+            __syncthreads();
+            for (int j = tid; j < kSeg + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+            __syncthreads();
+            seg_products<NT>(sA, sB, seglen, tot, wred);
+            if (tid < 64) r[blk * 64 + tid] = tot[tid];
+        }
+    }
+}
+
+// Exclusive prefix sums over the 64 lanes of a wave, plus the wave total.
+__device__ __forceinline__ double wave_excl_scan(double v, double& total)
+{
+    const int lane = threadIdx.x & 63;
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, kWave); if (lane >= o) incl += t; }
+    total = __shfl(incl, 63, kWave);
+    return incl - v;
+}
+
+// Per-chain state kept between the two combine kernels.
+constexpr int kChState = 6;   // mean, S, constant flag, head(64), tail(64), -
+
+// One wave per (parameter, kind).  grid (P, 2), block 64.
+__global__ __launch_bounds__(64) void k_diag_combine(const double* __restrict__ zb, const double* __restrict__ zt,
+                                                     i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
+                                                     int nseg, const double* __restrict__ rec,
+                                                     double* __restrict__ res, i64 P, unsigned* __restrict__ more,
+                                                     double* __restrict__ state, double* __restrict__ chstate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* cm = reinterpret_cast<double*>(smem);   // C   chain means
+    double* cq = cm + C;                             // C   sum (z - mean)^2
+    double* hm = cq + C;                             // 2C  half means
+    double* hq = hm + 2 * C;                         // 2C  half sums of squared deviations
+    const int lane = threadIdx.x;
+    const i64 p = blockIdx.x;
+    const int kind = blockIdx.y;
+    const i64 pk = p * 2 + kind;
+    const double* z = (kind ? zt : zb) + p * M;
+    const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
+    const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
+    const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
+
+    double covsum = 0.0;   // lane l: sum over chains of sum_i (z_i - m)(z_{i+l} - m)
+    for (int c = 0; c < C; ++c) {
+        const double* R = rec + ((pk * C + c) * (i64)nseg) * kSegRec;
+        double Pl = 0.0, S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0, Q = 0.0;
+        double vmin = INFINITY, vmax = -INFINITY;
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const double* r = R + (i64)sgm * kSegRec;
+            Pl += r[lane]; Q += r[0];
+            S += r[SG_S]; S0 += r[SG_S0]; Q0 += r[SG_Q0]; S1 += r[SG_S1]; Q1 += r[SG_Q1];
+            vmin = fmin(vmin, r[SG_MIN]); vmax = fmax(vmax, r[SG_MAX]);
+        }
+        const bool constant = !(vmin < vmax);
+        const double m = (n > 0) ? S / (double)n : 0.0;
+        const double* zc = z + off[c];
+        double th, tt;
+        const double head = wave_excl_scan((lane < n) ? zc[lane] : 0.0, th);            // sum_{i<l} z_i
+        const double tail = wave_excl_scan((lane < n) ? zc[n - 1 - lane] : 0.0, tt);    // sum_{i>=n-l} z_i
+        if (!constant && lane < n)
+            covsum += Pl - m * ((S - tail) + (S - head)) + (double)(n - lane) * m * m;
+        if (lane == 0) {
+            cm[c] = m;
+            cq[c] = constant ? 0.0 : Q - S * m;
+            const double m0 = (nh > 0) ? S0 / (double)nh : 0.0, m1 = (nh > 0) ? S1 / (double)nh : 0.0;
+            hm[2 * c] = m0; hm[2 * c + 1] = m1;
+            hq[2 * c] = constant ? 0.0 : fmax(Q0 - S0 * m0, 0.0);
+            hq[2 * c + 1] = constant ? 0.0 : fmax(Q1 - S1 * m1, 0.0);
+            double* cs = chstate + (pk * C + c) * kChState;
+            cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = th; cs[4] = tt;
+        }
+    }
+    __syncthreads();
+    __shared__ double bc[2];   // var_hat, mode (0: NaN, 1: var_hat == 0, 2: scan)
+    if (lane == 0) {
+        // ---- split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped ----
+        int ms = 0;
+        for (int k = 0; k < C; ++k) ms += (off[k + 1] - off[k] >= 2) ? 2 : 0;
+        double rhat;
+        if (ms < 2 || nh < 2) {
+            rhat = NAN;
+        } else {
+            double st = 0.0;
+            for (int k = 0; k < C; ++k)
+                if (off[k + 1] - off[k] >= 2) { st += hm[2 * k]; st += hm[2 * k + 1]; }
+            const double mt = st / (double)ms;
+            double sb = 0.0, sw = 0.0;
+            for (int k = 0; k < C; ++k)
+                if (off[k + 1] - off[k] >= 2) {
+                    const double a = hm[2 * k] - mt, b = hm[2 * k + 1] - mt;
+                    sb += a * a; sb += b * b;
+                    sw += hq[2 * k] / (double)(nh - 1);
+                    sw += hq[2 * k + 1] / (double)(nh - 1);
+                }
+            const double vb = (double)nh * sb / (double)(ms - 1);
+            const double vw = sw / (double)ms;
+            const double vh = (double)(nh - 1) / (double)nh * vw + vb / (double)nh;
+            rhat = (vw == 0.0) ? ((vb == 0.0) ? 1.0 : INFINITY) : sqrt(vh / vw);
+        }
+        res[f_rhat * P + p] = rhat;
+        // ---- ESS prologue (diagnostics.py:154-169) ----
+        double vh = 0.0, mode = 0.0;
+        if (!(C == 0 || n < 2)) {
+            double st = 0.0;
+            for (int k = 0; k < C; ++k) st += cm[k];
+            const double mt = st / (double)C;
+            double sb = 0.0, sw = 0.0;
+            for (int k = 0; k < C; ++k) {
+                const double a = cm[k] - mt;
+                sb += a * a;
+                sw += fmax(cq[k], 0.0) / (double)(n - 1);
+            }
+            const double vb = (C > 1) ? (double)n * sb / (double)(C - 1) : 0.0;
+            const double vw = sw / (double)C;
+            vh = (double)(n - 1) / (double)n * vw + vb / (double)n;
+            mode = (vh == 0.0) ? 1.0 : 2.0;
+        }
+        bc[0] = vh; bc[1] = mode;
+    }
+    __syncthreads();
+    const double vh = bc[0];
+    const int mode = (int)bc[1];
+    // ---- rho terms of lags 1..63, all lanes at once; the first negative one stops the sum
+    //      (diagnostics.py:171-177).  The prefix is summed with a wave tree instead of left to right.
+    double rho = 0.0;
+    bool neg = false;
+    const bool valid = mode == 2 && lane >= 1 && lane < n;
+    if (valid) {
+        rho = (covsum / (double)(n - lane)) / ((double)C * vh);
+        neg = rho < 0.0;
+    }
+    const unsigned long long negmask = __ballot(neg);
+    const int first = negmask ? (__ffsll((long long)negmask) - 1) : 64;      // lag of the first negative rho
+    const double rho_sum = wave_sum((valid && lane < first) ? rho : 0.0);
+    const int nvalid = (int)__popcll(__ballot(valid && lane < first));
+    if (lane != 0) return;
+    unsigned cont = 0u;
+    if (mode == 0) {
+        res[f_ess * P + p] = NAN;
+        res[f_lag * P + p] = 0.0;
+    } else if (mode == 1) {
+        res[f_ess * P + p] = (double)((i64)C * n);
+        res[f_lag * P + p] = 0.0;
+    } else {
+        cont = (first == 64 && n > 64) ? 1u : 0u;
+        if (!cont) {
+            res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+            res[f_lag * P + p] = (double)nvalid;
+        }
+    }
+    more[pk] = cont;
+    double* stp = state + pk * 4;
+    stp[0] = rho_sum; stp[1] = (double)nvalid; stp[2] = vh;
+}
+
+// Continuation for flagged pairs: lags 64..255 from the second k_acov_seg pass, then (very sticky
+// chains only) a direct deviation-product loop over L2 from lag 256.  grid (P, 2), block 256.
+__global__ __launch_bounds__(256) void k_diag_combine2(const double* __restrict__ zb,
+                                                       const double* __restrict__ zt, i64 M,
+                                                       const i64* __restrict__ off, int C, i64 n, int nseg,
+                                                       const double* __restrict__ rec2,
+                                                       const unsigned* __restrict__ more,
+                                                       const double* __restrict__ state,
+                                                       const double* __restrict__ chstate,
+                                                       double* __restrict__ res, i64 P)
+{
+    const i64 p = blockIdx.x;
+    const int kind = blockIdx.y;
+    const i64 pk = p * 2 + kind;
+    if (more[pk] == 0u) return;
+    __shared__ double tot[64];
+    __shared__ double wred[4 * 64];
+    __shared__ double ctl[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const double* z = (kind ? zt : zb) + p * M;
+    const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
+    const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
+    double rho_sum = state[pk * 4 + 0];
+    i64 terms = (i64)state[pk * 4 + 1];
+    const double vhat = state[pk * 4 + 2];
+    bool stop = false;
+
+    // ---- lags 64..255: wave 0 combines the records block by block ----
+    // hb[c] / tb[c]: running sums of the first / last `lb` draws of chain c (head / tail bases)
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    double* hb = reinterpret_cast<double*>(smem2);
+    double* tb = hb + C;
+    for (int c = tid; c < C; c += 256) { hb[c] = chstate[(pk * C + c) * kChState + 3]; tb[c] = chstate[(pk * C + c) * kChState + 4]; }
+    __syncthreads();
+    for (int blk = 0; blk < kMoreBlocks && !stop; ++blk) {
+        const i64 lb = 64 + 64 * blk;
+        if (lb >= n) break;
+        if (w == 0) {
+            double covsum = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double* cs = chstate + (pk * C + c) * kChState;
+                const double* zc = z + off[c];
+                double th, tt;
+                const double hx = wave_excl_scan((lb + lane < n) ? zc[lb + lane] : 0.0, th);
+                const double tx = wave_excl_scan((lb + lane < n) ? zc[n - 1 - (lb + lane)] : 0.0, tt);
+                const double head = hb[c] + hx, tail = tb[c] + tx;   // sums of the first / last (lb + lane) draws
+                if (lane == 0) { hb[c] += th; tb[c] += tt; }
+                if (cs[2] != 0.0) continue;                       // constant chain: zero deviations
+                const double m = cs[0], S = cs[1];
+                double Pl = 0.0;
+                for (int sgm = 0; sgm < nseg; ++sgm)
+                    Pl += rec2[((pk * C + c) * (i64)nseg + sgm) * (64 * kMoreBlocks) + blk * 64 + lane];
+                const i64 lag = lb + lane;
+                if (lag < n) covsum += Pl - m * ((S - tail) + (S - head)) + (double)(n - lag) * m * m;
+            }
+            const i64 lag = lb + lane;
+            const bool valid = lag < n;
+            const double rho = valid ? (covsum / (double)(n - lag)) / ((double)C * vhat) : 0.0;
+            const unsigned long long negmask = __ballot(valid && rho < 0.0);
+            const int first = negmask ? (__ffsll((long long)negmask) - 1) : 64;
+            const double add = wave_sum((valid && lane < first) ? rho : 0.0);
+            const int cnt = (int)__popcll(__ballot(valid && lane < first));
+            if (lane == 0) { ctl[0] = (first < 64) ? 1.0 : 0.0; ctl[1] = add; tot[0] = (double)cnt; }
+        }
+        __syncthreads();
+        rho_sum += ctl[1];
+        terms += (i64)tot[0];
+        stop = ctl[0] != 0.0;
+        __syncthreads();
+    }
+    // ---- beyond lag 255: direct products of deviations, 64 lags per round, 4 waves over i ----
+    for (i64 lb = 64 + 64 * kMoreBlocks; lb < n && !stop; lb += 64) {
+        const i64 lag = lb + lane;
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double* cs = chstate + (pk * C + c) * kChState;
+            if (cs[2] != 0.0) continue;
+            const double m = cs[0];
+            const double* zc = z + off[c];
+            for (i64 i = w; i + lag < n; i += 4) acc = fma(zc[i] - m, zc[i + lag] - m, acc);
+        }
+        __syncthreads();
+        wred[w * 64 + lane] = acc;
+        __syncthreads();
+        if (tid < 64) tot[tid] = wred[tid] + wred[64 + tid] + wred[128 + tid] + wred[192 + tid];
+        __syncthreads();
+        if (tid == 0) {
+            double st = 0.0;
+            for (i64 l = 0; l < 64 && lb + l < n; ++l) {
+                const double rho = (tot[l] / (double)(n - (lb + l))) / ((double)C * vhat);
+                if (rho < 0.0) { st = 1.0; break; }
+                rho_sum += rho;
+                ++terms;
+            }
+            ctl[0] = st;
+        }
+        __syncthreads();
+        stop = ctl[0] != 0.0;
+    }
+    if (tid == 0) {
+        res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+        res[f_lag * P + p] = (double)terms;
+    }
+}
+
+}  // namespace mcr

@@ -9,7 +9,7 @@
 //   k_rank_z        tie-averaged ranks -> z = Phi^-1((r-0.5)/M), scattered to time order (a7)
 //   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort) (a8)
 //   k_rank_z        same for the folded values
-//   k_diag          split R-hat + ESS (first-negative-rho truncation) for bulk and folded z (a9-a13)
+//   k_acov_seg / k_diag_combine (mcr_diag.hpp)  split R-hat + ESS for bulk and folded z (a9-a13)
 //   k_finalize      mean/std from partials, rhat = pymax(bulk, tail), packs the result table
 //
 // (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
@@ -865,489 +865,6 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
     const u32 t = idx[p * M + i];
     z[p * M + t] = inv_cdf(pr);
     if (rank_out) rank_out[p * M + t] = r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Split R-hat and ESS of one (parameter, kind) from z in time order.  blockIdx.y: 0 = bulk z,
-// 1 = folded z.  Chain c is z[off[c] .. off[c+1]); n = min chain length, nh = min half length
-// (over chains with at least 2 draws), as the reference truncates (diagnostics.py:140, :158).
-//   _split_chains + _rhat   src/mcmc_ref/diagnostics.py:76-85, 136-151
-//   _ess + _autocorr        src/mcmc_ref/diagnostics.py:154-193  (UNSPLIT chains, lag loop
-//                           stops at the first negative rho; rho normalised by (n - lag))
-// Lags are evaluated in blocks (16 first, then 64): lane = (lag, i-phase), the deviations of one
-// chain are staged in LDS (STAGE) or read through L2 (long chains).  The rho terms of a block
-// are then accumulated left-to-right by one thread, exactly like the reference's loop.
-// ------------------------------------------------------------------------------------------------
-template <int NT, bool STAGE>
-__global__ __launch_bounds__(NT) void k_diag(const double* __restrict__ zb, const double* __restrict__ zt,
-                                             i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
-                                             double* __restrict__ res, i64 P)
-{
-    constexpr int NW = NT / kWave;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem);  // NW
-    double* cm = red + NW;                           // C   chain means
-    double* cv = cm + C;                             // C   chain variances (ddof=1)
-    double* hm = cv + C;                             // 2C  half-chain means
-    double* hv = hm + 2 * C;                         // 2C  half-chain variances
-    double* tot = hv + 2 * C;                        // 64  per-lag totals
-    double* wred = tot + 64;                         // NW*64
-    double* ctl = wred + NW * 64;                    // 4: var_hat, run flag
-    double* dch = ctl + 4;                           // n (STAGE only)
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const i64 p = blockIdx.x;
-    const int kind = blockIdx.y;
-    const double* z = (kind ? zt : zb) + p * M;
-    const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
-    const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
-    const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-
-    // ---- per-chain and per-half means / variances (two-pass, like _variance) ----
-    for (int c = 0; c < C; ++c) {
-        const double* zc = z + off[c];
-        const i64 nc = off[c + 1] - off[c], hc = nc / 2;
-        double sf = 0.0, s0 = 0.0, s1 = 0.0;
-        for (i64 i = tid; i < n; i += NT) sf += zc[i];
-        if (hc > 0) {
-            for (i64 i = tid; i < nh; i += NT) { s0 += zc[i]; s1 += zc[hc + i]; }
-        }
-        sf = block_sum<NT>(sf, red);
-        s0 = block_sum<NT>(s0, red);
-        s1 = block_sum<NT>(s1, red);
-        const double mf = (n > 0) ? sf / (double)n : 0.0;
-        const double m0 = (nh > 0) ? s0 / (double)nh : 0.0, m1 = (nh > 0) ? s1 / (double)nh : 0.0;
-        double qf = 0.0, q0 = 0.0, q1 = 0.0;
-        for (i64 i = tid; i < n; i += NT) { const double d = zc[i] - mf; qf = fma(d, d, qf); }
-        if (hc > 0) {
-            for (i64 i = tid; i < nh; i += NT) {
-                const double d0 = zc[i] - m0, d1 = zc[hc + i] - m1;
-                q0 = fma(d0, d0, q0); q1 = fma(d1, d1, q1);
-            }
-        }
-        qf = block_sum<NT>(qf, red);
-        q0 = block_sum<NT>(q0, red);
-        q1 = block_sum<NT>(q1, red);
-        if (tid == 0) {
-            cm[c] = mf;
-            cv[c] = (n >= 2) ? qf / (double)(n - 1) : 0.0;
-            hm[2 * c] = m0; hm[2 * c + 1] = m1;
-            hv[2 * c] = (nh >= 2) ? q0 / (double)(nh - 1) : 0.0;
-            hv[2 * c + 1] = (nh >= 2) ? q1 / (double)(nh - 1) : 0.0;
-        }
-    }
-    __syncthreads();
-
-    if (tid == 0) {
-        // ---- split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped ----
-        int ms = 0;
-        for (int c = 0; c < C; ++c) ms += (off[c + 1] - off[c] >= 2) ? 2 : 0;
-        double rhat;
-        if (ms < 2 || nh < 2) {
-            rhat = NAN;
-        } else {
-            double st = 0.0;
-            for (int c = 0; c < C; ++c)
-                if (off[c + 1] - off[c] >= 2) { st += hm[2 * c]; st += hm[2 * c + 1]; }
-            const double mt = st / (double)ms;
-            double sb = 0.0, sw = 0.0;
-            for (int c = 0; c < C; ++c)
-                if (off[c + 1] - off[c] >= 2) {
-                    const double a = hm[2 * c] - mt, b = hm[2 * c + 1] - mt;
-                    sb += a * a; sb += b * b;
-                    sw += hv[2 * c]; sw += hv[2 * c + 1];
-                }
-            const double vb = (double)nh * sb / (double)(ms - 1);
-            const double vw = sw / (double)ms;
-            const double vh = (double)(nh - 1) / (double)nh * vw + vb / (double)nh;
-            rhat = (vw == 0.0) ? ((vb == 0.0) ? 1.0 : INFINITY) : sqrt(vh / vw);
-        }
-        res[f_rhat * P + p] = rhat;
-        // ---- ESS prologue (diagnostics.py:154-169) ----
-        double run = 0.0, vh = 0.0;
-        if (C == 0 || n < 2) {
-            res[f_ess * P + p] = NAN;
-            res[f_lag * P + p] = 0.0;
-        } else {
-            double st = 0.0;
-            for (int c = 0; c < C; ++c) st += cm[c];
-            const double mt = st / (double)C;
-            double sb = 0.0, sw = 0.0;
-            for (int c = 0; c < C; ++c) { const double a = cm[c] - mt; sb += a * a; sw += cv[c]; }
-            const double vb = (C > 1) ? (double)n * sb / (double)(C - 1) : 0.0;
-            const double vw = sw / (double)C;
-            vh = (double)(n - 1) / (double)n * vw + vb / (double)n;
-            if (vh == 0.0) {
-                res[f_ess * P + p] = (double)((i64)C * n);
-                res[f_lag * P + p] = 0.0;
-            } else {
-                run = 1.0;
-            }
-        }
-        ctl[0] = vh; ctl[1] = run;
-    }
-    __syncthreads();
-    if (ctl[1] == 0.0) return;
-    const double vhat = ctl[0];
-
-    double rho_sum = 0.0;  // thread 0 only
-    i64 terms = 0;
-    i64 lag0 = 1;
-    int LB = 16;
-    while (lag0 < n) {
-        const int nl = (int)((n - lag0 < (i64)LB) ? n - lag0 : (i64)LB);
-        const int ll = lane % LB, r = lane / LB, stride = kWave / LB;
-        const i64 lag = lag0 + ll;
-        double acc = 0.0;
-        for (int c = 0; c < C; ++c) {
-            const double* zc = z + off[c];
-            const double mean = cm[c];
-            if (STAGE) {
-                __syncthreads();
-                for (i64 i = tid; i < n; i += NT) dch[i] = zc[i] - mean;
-                __syncthreads();
-            }
-            if (ll < nl) {
-                for (i64 i = (i64)w * stride + r; i + lag < n; i += (i64)NW * stride) {
-                    const double a = STAGE ? dch[i] : zc[i] - mean;
-                    const double b = STAGE ? dch[i + lag] : zc[i + lag] - mean;
-                    acc = fma(a, b, acc);
-                }
-            }
-        }
-        for (int o = LB; o < kWave; o <<= 1) acc += __shfl_xor(acc, o, kWave);
-        __syncthreads();
-        if (lane < LB) wred[w * 64 + lane] = acc;
-        __syncthreads();
-        if (tid < nl) {
-            double t = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
-            tot[tid] = t;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double stop = 0.0;
-            for (int l = 0; l < nl; ++l) {
-                const double cov = tot[l] / (double)(n - (lag0 + l));
-                const double rho = cov / ((double)C * vhat);
-                if (rho < 0.0) { stop = 1.0; break; }
-                rho_sum += rho;
-                ++terms;
-            }
-            ctl[2] = stop;
-        }
-        __syncthreads();
-        if (ctl[2] != 0.0) break;
-        lag0 += nl;
-        LB = 64;
-    }
-    if (tid == 0) {
-        res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
-        res[f_lag * P + p] = (double)terms;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_chain_stats + k_diag_combine: the same statistics as k_diag, parallel over chains and VALU-bound instead of LDS-bound.
-//
-//   grid (C, P, 2): one workgroup per (chain, parameter, kind).  It stages its chain ONCE in LDS
-//   (swizzled: 2 pad doubles per 8, so that 16-byte reads at 64-byte lane spacing hit distinct
-//   banks), computes the chain / half-chain means and two-pass variances, then the raw
-//   autocovariance sums of lags 0..63 with an 8 (i) x 8 (lag) register tile per lane:
-//   12 ds_read_b128 feed 64 fp64 FMAs per lane, so the loop is bound by the fp64 VALU, not LDS.
-//   Lag 0 is the chain's sum of squared deviations, so the variance costs no extra pass.
-//   Each workgroup writes a 72-double record; k_diag_combine (next launch) folds the C records of
-//   a (parameter, kind) into split R-hat, var_hat and the rho terms of lags 1..63 left to right,
-//   and -- only for the few parameters whose first negative rho lies beyond lag 63 -- continues
-//   64 lags at a time.  (A last-arriver hand-off inside one launch was measured slower: an
-//   agent-scope release per workgroup is an L2 write-back, 9200 of them serialise.)
-//   Reference: src/mcmc_ref/diagnostics.py:76-85, 136-193.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ i64 pos8(i64 j) { return j + ((j >> 3) << 1); }
-
-// Three deterministic block sums with one barrier pair.  `red` holds 3 * NT/64 doubles.
-template <int NT>
-__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red)
-{
-    constexpr int NW = NT / kWave;
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        red[w] = a; red[NW + w] = b; red[2 * NW + w] = c;
-    }
-    __syncthreads();
-    double ra = 0.0, rb = 0.0, rc = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { ra += red[w]; rb += red[NW + w]; rc += red[2 * NW + w]; }
-    a = ra; b = rb; c = rc;
-    __syncthreads();
-}
-
-constexpr int kRecDoubles = 72;  // mean, qf, m0, m1, q0, q1, -, - , acov[64]
-
-// Raw autocovariance sums of lags lb..lb+63 (lb % 64 == 0) of the zero-padded, swizzled chain d.
-// Result in tot[0..63] (accumulated when `accumulate`).  All NT threads must call it.
-template <int NT>
-__device__ __forceinline__ void acov_block(const double* __restrict__ d, i64 n, i64 lb, double* tot,
-                                           double* wred, bool accumulate)
-{
-    constexpr int NW = NT / kWave;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane & 7, ph = lane >> 3;
-    double acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-    const i64 nit = (n + 63) >> 6;
-    for (i64 it = w; it < nit; it += NW) {
-        const i64 i0 = (it << 6) + (ph << 3);
-        const i64 s = i0 + lb + (g << 3);
-        if (s < n) {
-            const double2* pa = reinterpret_cast<const double2*>(d + 10 * (i0 >> 3));
-            const double2* pb = reinterpret_cast<const double2*>(d + 10 * (s >> 3));
-            double a[8], b[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const double2 v = pa[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const double2 v = pb[j]; b[2 * j] = v.x; b[2 * j + 1] = v.y; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const double2 v = pb[5 + j]; b[8 + 2 * j] = v.x; b[9 + 2 * j] = v.y; }
-#pragma unroll
-            for (int li = 0; li < 8; ++li)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[li] = fma(a[k], b[k + li], acc[li]);
-        }
-    }
-#pragma unroll
-    for (int li = 0; li < 8; ++li) {
-        acc[li] += __shfl_xor(acc[li], 8, kWave);
-        acc[li] += __shfl_xor(acc[li], 16, kWave);
-        acc[li] += __shfl_xor(acc[li], 32, kWave);
-    }
-    __syncthreads();  // wred / tot may still be in use
-    if (ph == 0) {
-#pragma unroll
-        for (int li = 0; li < 8; ++li) wred[w * 64 + (g << 3) + li] = acc[li];
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double t = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
-        tot[tid] = accumulate ? tot[tid] + t : t;
-    }
-    __syncthreads();
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void k_chain_stats(const double* __restrict__ zb, const double* __restrict__ zt,
-                                                    i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
-                                                    double* __restrict__ rec)
-{
-    constexpr int NW = NT / kWave;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem);  // 48
-    double* tot = red + 48;                          // 64
-    double* wred = tot + 64;                         // NW*64
-    double* ctl = wred + NW * 64;                    // 8
-    double* dch = ctl + 8;                           // swizzled chain, zero padded
-
-    const int tid = threadIdx.x, w = tid >> 6;
-    const int c = blockIdx.x, kind = blockIdx.z;
-    const i64 p = blockIdx.y;
-    const double* z = (kind ? zt : zb) + p * M;
-    const double* zc = z + off[c];
-    const i64 nc = off[c + 1] - off[c], hc = nc / 2;
-    const i64 hspan = (hc > 0) ? hc + nh : 0;
-    const i64 nload = (n > hspan) ? n : hspan;                       // <= nc
-    const i64 lz = ((nload + 63) & ~(i64)63) + 80;                   // logical length incl. zero pad
-
-    // ---- stage the chain (8 global loads in flight per lane), sums for the means ----
-    double sf = 0.0, s0 = 0.0, s1 = 0.0;
-    for (i64 base = 0; base < lz; base += (i64)NT * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const i64 i = base + (i64)u * NT + tid;
-#if defined(MCR_EXP) && MCR_EXP == 2
-            v[u] = (double)i;
-#else
-            v[u] = (i < nload) ? zc[i] : 0.0;
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const i64 i = base + (i64)u * NT + tid;
-            if (i < lz) {
-                if (i < n) sf += v[u];
-                if (hc > 0) {
-                    if (i < nh) s0 += v[u];
-                    if (i >= hc && i < hc + nh) s1 += v[u];
-                }
-                dch[pos8(i)] = v[u];
-            }
-        }
-    }
-    block_sum3<NT>(sf, s0, s1, red);
-    const double mf = (n > 0) ? sf / (double)n : 0.0;
-    const double m0 = (nh > 0) ? s0 / (double)nh : 0.0, m1 = (nh > 0) ? s1 / (double)nh : 0.0;
-    // ---- half-chain squared deviations (two-pass, like _variance) ----
-    double q0 = 0.0, q1 = 0.0, qdummy = 0.0;
-    if (hc > 0) {
-        for (i64 i = tid; i < nh; i += NT) {
-            const double d0 = dch[pos8(i)] - m0, d1 = dch[pos8(hc + i)] - m1;
-            q0 = fma(d0, d0, q0); q1 = fma(d1, d1, q1);
-        }
-    }
-    block_sum3<NT>(q0, q1, qdummy, red);   // ends with a barrier: all reads of the raw chain are done
-    // ---- deviations from the chain mean, zero beyond n ----
-    for (i64 i = tid; i < lz; i += NT) {
-        const i64 q = pos8(i);
-        dch[q] = (i < n) ? dch[q] - mf : 0.0;
-    }
-    __syncthreads();
-#if !defined(MCR_EXP) || MCR_EXP != 1
-    acov_block<NT>(dch, n, 0, tot, wred, false);
-#endif
-
-    // ---- publish this chain's record ----
-    double* myrec = rec + ((p * 2 + kind) * C + c) * kRecDoubles;
-    if (tid < 64) myrec[8 + tid] = tot[tid];
-    if (tid == 0) {
-        myrec[0] = mf; myrec[1] = tot[0]; myrec[2] = m0; myrec[3] = m1; myrec[4] = q0; myrec[5] = q1;
-    }
-}
-
-// Combine the C chain records of one (parameter, kind): split R-hat, var_hat, the rho terms of
-// lags 1..63 left to right; only when the first negative rho lies beyond lag 63 does the workgroup
-// stage chains itself and continue 64 lags at a time.  grid (P, 2).  The kernel boundary after
-// k_chain_stats is the only synchronisation (no in-launch hand-off).
-template <int NT>
-__global__ __launch_bounds__(NT) void k_diag_combine(const double* __restrict__ zb,
-                                                     const double* __restrict__ zt, i64 M,
-                                                     const i64* __restrict__ off, int C, i64 n, i64 nh,
-                                                     i64 lz, const double* __restrict__ rec,
-                                                     double* __restrict__ res, i64 P)
-{
-    constexpr int NW = NT / kWave;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem);  // 48
-    double* tot = red + 48;                          // 64
-    double* wred = tot + 64;                         // NW*64
-    double* ctl = wred + NW * 64;                    // 8
-    double* dch = ctl + 8;                           // swizzled chain, zero padded
-    const int tid = threadIdx.x;
-    const i64 p = blockIdx.x;
-    const int kind = blockIdx.y;
-    const double* z = (kind ? zt : zb) + p * M;
-    const double* R = rec + ((p * 2 + kind) * C) * kRecDoubles;
-    const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
-    const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
-    const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-    if (tid < 64) {  // lag totals over chains, in chain order
-        double t = 0.0;
-        for (int k = 0; k < C; ++k) t += R[k * kRecDoubles + 8 + tid];
-        tot[tid] = t;
-    }
-    __syncthreads();
-    double rho_sum = 0.0;  // thread 0 only
-    i64 terms = 0;
-    if (tid == 0) {
-        // split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped
-        int ms = 0;
-        for (int k = 0; k < C; ++k) ms += (off[k + 1] - off[k] >= 2) ? 2 : 0;
-        double rhat;
-        if (ms < 2 || nh < 2) {
-            rhat = NAN;
-        } else {
-            double st = 0.0;
-            for (int k = 0; k < C; ++k)
-                if (off[k + 1] - off[k] >= 2) { st += R[k * kRecDoubles + 2]; st += R[k * kRecDoubles + 3]; }
-            const double mt = st / (double)ms;
-            double sb = 0.0, sw = 0.0;
-            for (int k = 0; k < C; ++k)
-                if (off[k + 1] - off[k] >= 2) {
-                    const double a = R[k * kRecDoubles + 2] - mt, b = R[k * kRecDoubles + 3] - mt;
-                    sb += a * a; sb += b * b;
-                    sw += R[k * kRecDoubles + 4] / (double)(nh - 1);
-                    sw += R[k * kRecDoubles + 5] / (double)(nh - 1);
-                }
-            const double vb = (double)nh * sb / (double)(ms - 1);
-            const double vw = sw / (double)ms;
-            const double vh = (double)(nh - 1) / (double)nh * vw + vb / (double)nh;
-            rhat = (vw == 0.0) ? ((vb == 0.0) ? 1.0 : INFINITY) : sqrt(vh / vw);
-        }
-        res[f_rhat * P + p] = rhat;
-        // ESS prologue (diagnostics.py:154-169)
-        double state = 0.0, vh = 0.0;  // state: 0 = finished, 1 = more lags needed
-        if (C == 0 || n < 2) {
-            res[f_ess * P + p] = NAN;
-            res[f_lag * P + p] = 0.0;
-        } else {
-            double st = 0.0;
-            for (int k = 0; k < C; ++k) st += R[k * kRecDoubles];
-            const double mt = st / (double)C;
-            double sb = 0.0, sw = 0.0;
-            for (int k = 0; k < C; ++k) {
-                const double a = R[k * kRecDoubles] - mt;
-                sb += a * a;
-                sw += R[k * kRecDoubles + 1] / (double)(n - 1);
-            }
-            const double vb = (C > 1) ? (double)n * sb / (double)(C - 1) : 0.0;
-            const double vw = sw / (double)C;
-            vh = (double)(n - 1) / (double)n * vw + vb / (double)n;
-            if (vh == 0.0) {
-                res[f_ess * P + p] = (double)((i64)C * n);
-                res[f_lag * P + p] = 0.0;
-            } else {
-                state = 1.0;
-                for (i64 lag = 1; lag < 64 && lag < n; ++lag) {
-                    const double rho = (tot[lag] / (double)(n - lag)) / ((double)C * vh);
-                    if (rho < 0.0) { state = 0.0; break; }
-                    rho_sum += rho;
-                    ++terms;
-                }
-                if (state == 1.0 && n <= 64) state = 0.0;  // ran out of lags
-                if (state == 0.0) {
-                    res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
-                    res[f_lag * P + p] = (double)terms;
-                }
-            }
-        }
-        ctl[1] = state; ctl[2] = vh;
-    }
-    __syncthreads();
-    if (ctl[1] == 0.0) return;
-    // ---- rare: the first negative rho lies beyond lag 63; continue 64 lags at a time ----
-    const double vhat = ctl[2];
-    for (i64 lb = 64; lb < n; lb += 64) {
-        for (int k = 0; k < C; ++k) {
-            const double* zk = z + off[k];
-            const double mean = R[k * kRecDoubles];
-            __syncthreads();
-            for (i64 i = tid; i < n; i += NT) dch[pos8(i)] = zk[i] - mean;   // pads stay zero
-            for (i64 i = n + tid; i < lz; i += NT) dch[pos8(i)] = 0.0;
-            __syncthreads();
-            acov_block<NT>(dch, n, lb, tot, wred, k > 0);
-        }
-        if (tid == 0) {
-            double stop = 0.0;
-            for (i64 l = 0; l < 64 && lb + l < n; ++l) {
-                const double rho = (tot[l] / (double)(n - (lb + l))) / ((double)C * vhat);
-                if (rho < 0.0) { stop = 1.0; break; }
-                rho_sum += rho;
-                ++terms;
-            }
-            ctl[3] = stop;
-        }
-        __syncthreads();
-        if (ctl[3] != 0.0) break;
-    }
-    if (tid == 0) {
-        res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
-        res[f_lag * P + p] = (double)terms;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
