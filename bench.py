@@ -32,15 +32,24 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # (DESIGN.md "Kernels and rooflines").  Intermediate traffic a kernel causes
 # beyond these is implementation overhead and shows up as a lower fraction.
 ALG_BYTES_PER_PD = {
-    "k_tile_sort": 8.0,     # the one compulsory read of the draw tensor
-    "k_merge": 8.0,         # (per pass) re-reads the keys it merges; idx payload is overhead
-    "k_fold_merge": 8.0,
-    "k_rank_z": 8.0,        # the 8-byte z it must produce per draw (keys are intermediates)
-    "k_chain_stats": 16.0,  # reads z_bulk and z_tail once each (chain moments + 64-lag autocovariance)
-    "k_diag": 16.0,         # legacy single-kernel R-hat/ESS path (long chains): same contract
-    "k_ingest": 16.0,       # read + write of the layout change
+    "k_tile_sort": 8.0,      # the one compulsory read of the draw tensor (its sorted tiles are intermediates)
+    "k_bucket_merge": 8.0,   # the 8-byte bulk z it must produce per draw (sorted order is an intermediate)
+    "k_fold_merge": 8.0,     # the 8-byte folded z it must produce per draw
+    "k_acov_seg": 16.0,      # reads z_bulk and z_tail once each
+    "k_merge": 8.0,          # (long-array path, per pass) re-reads the keys it merges
+    "k_rank_z": 8.0,         # (long-array path) the z it must produce
+    "k_ingest": 16.0,        # read + write of the layout change
     "k_moments": 8.0,
 }
+
+
+def alg_bytes(name: str, es: int) -> float:
+    """Algorithmic bytes per param-draw of one launch of kernel `name` for element size `es`."""
+    if name in ("k_tile_sort", "k_moments"):
+        return float(es)                  # the compulsory read scales with the input dtype
+    if name == "k_ingest":
+        return float(es) + 8.0
+    return ALG_BYTES_PER_PD.get(name, 0.0)
 
 
 def parse_args():
@@ -119,13 +128,20 @@ def main():
         return last
 
     run(a.warmup)
-    ctx.profile(True)
-    ctx.profile_reset()
+    # ---- timed region: exactly K steps (captured hipGraph replays, up to 4 in flight) ----
     barrier()
     t0 = time.perf_counter()
     last = run(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    # ---- same K steps again with a HIP event pair around every kernel launch (per-kernel roofline);
+    #      events cannot sit inside a graph replay, so this pass launches the kernels directly ----
+    ctx.profile(True)
+    ctx.profile_reset()
+    t1 = time.perf_counter()
+    run(a.steps)
+    ctx.sync()
+    elapsed_prof = time.perf_counter() - t1
     prof = ctx.profile_get()
     ctx.profile(False)
 
@@ -193,13 +209,13 @@ def main():
         dom, dom_ms = None, -1.0
         for name, r in prof.items():
             avg_ms = r["total_ms"] / max(r["launches"], 1)
-            alg = ALG_BYTES_PER_PD.get(name, 0.0) * (es / 8.0 if name in ("k_tile_sort", "k_moments") else 1.0)
+            alg = alg_bytes(name, es)
             kern[name] = {"launches_per_step": r["launches"] / a.steps, "avg_us": round(avg_ms * 1e3, 2),
                           "alg_GBps": round(alg * pd_step / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None}
             if r["total_ms"] > dom_ms and name in ALG_BYTES_PER_PD:
                 dom, dom_ms = name, r["total_ms"]
         dom_avg_s = prof[dom]["total_ms"] / prof[dom]["launches"] * 1e-3
-        dom_alg = ALG_BYTES_PER_PD[dom] * (es / 8.0 if dom in ("k_tile_sort", "k_moments") else 1.0) * pd_step
+        dom_alg = alg_bytes(dom, es) * pd_step
         traffic = None
         tf = ROOT / "profiles" / "pmc_traffic.json"
         if tf.exists():
@@ -219,6 +235,7 @@ def main():
                        "layout": a.layout, "statistics": "mean,std,q5,q50,q95,split_rhat,ess_bulk,ess_tail",
                        "sharding": f"independent models, {world} rank(s), RCCL all_gather of summaries"},
             "validated": valid, "max_rel_err": worst,
+            "ms_per_step_event_pass": elapsed_prof / a.steps * 1e3,
             "pipeline_alg_GBps": value / world * es / 1e9,
             "pipeline_frac_of_hbm": value / world * es / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -49,6 +49,12 @@ struct Slot {
     std::vector<Chunk> chunks;
 };
 
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    hipGraphExec_t exec = nullptr;
+    std::vector<Chunk> chunks;
+};
+
 char g_init_err[512] = "";
 
 }  // namespace
@@ -68,6 +74,11 @@ struct mcr_ctx {
     std::vector<hipEvent_t> free_ev;
     int64_t k_launches[K_COUNT] = {0};
     double k_ms[K_COUNT] = {0};
+    // hipGraph cache: the launch sequence of one summarize call is static for a given shape,
+    // buffer set and slot, so it is captured once and replayed (removes ~5 us of host launch gap
+    // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
+    bool graph_on = true;
+    std::vector<GraphEntry> graphs;
 };
 
 namespace {
@@ -131,10 +142,18 @@ void prof_resolve(mcr_ctx* ctx)
                         hipGetErrorString(le_));                                               \
     } while (0)
 
+void drop_graphs(mcr_ctx* ctx)   // stream must be idle
+{
+    for (GraphEntry& g : ctx->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    ctx->graphs.clear();
+}
+
 int ensure_ws(mcr_ctx* ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return MCR_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs(ctx);
     if (ctx->ws) { hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     const size_t want = bytes + (bytes >> 3);  // a little slack so near-equal shapes do not realloc
     hipError_t e = hipMalloc(&ctx->ws, want);
@@ -151,6 +170,10 @@ int ensure_ws(mcr_ctx* ctx, size_t bytes)
 
 int ensure_slot(mcr_ctx* ctx, Slot& s, size_t res_doubles, size_t off_entries)
 {
+    if (res_doubles > s.res_cap || off_entries > s.off_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        drop_graphs(ctx);
+    }
     if (res_doubles > s.res_cap) {
         if (s.d_res) hipFree(s.d_res);
         if (s.h_res) hipHostFree(s.h_res);
@@ -438,51 +461,91 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
         rc = ensure_slot(ctx, s, (size_t)R * (size_t)P, (size_t)C + 1);
         if (rc) return rc;
         for (i64 c = 0; c <= C; ++c) s.h_off[c] = c * N;
-        HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
-        for (i64 p0 = 0; p0 < P; p0 += pcmax) {
-            const i64 pc = (P - p0 < pcmax) ? P - p0 : pcmax;
-            Carve cv{reinterpret_cast<char*>(ctx->ws)};
-            PipeIn a{};
-            a.M = M; a.pc = pc; a.C = (int)C; a.d_off = s.d_off; a.n = N; a.nh = (N >= 2) ? N / 2 : 0; a.q = q;
-            a.ntiles = wp.ntiles;
-            a.kA = cv.take<double>((size_t)pc * M); a.kB = cv.take<double>((size_t)pc * M);
-            a.iA = cv.take<u32>((size_t)pc * M);    a.iB = cv.take<u32>((size_t)pc * M);
-            a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
-            a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
-            a.split = cv.take<i64>((size_t)pc);
-            {
-                const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((N + kSeg - 1) / kSeg + 1);
-                a.rec = cv.take<double>((size_t)pc * 2 * cc * ns * kSegRec);
-                a.rec2 = cv.take<double>((size_t)pc * 2 * cc * ns * 64 * kMoreBlocks);
-                a.chstate = cv.take<double>((size_t)pc * 2 * cc * kChState);
-                a.more = cv.take<unsigned>((size_t)pc * 2);
-                a.state = cv.take<double>((size_t)pc * 2 * 4);
+        const bool do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
+                             out->lag_bulk || out->lag_tail;
+        // Everything below only enqueues stream work with arguments that are a pure function of `key`.
+        auto issue = [&]() -> int {
+            HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+            for (i64 p0 = 0; p0 < P; p0 += pcmax) {
+                const i64 pc = (P - p0 < pcmax) ? P - p0 : pcmax;
+                Carve cv{reinterpret_cast<char*>(ctx->ws)};
+                PipeIn a{};
+                a.M = M; a.pc = pc; a.C = (int)C; a.d_off = s.d_off; a.n = N; a.nh = (N >= 2) ? N / 2 : 0; a.q = q;
+                a.ntiles = wp.ntiles;
+                a.kA = cv.take<double>((size_t)pc * M); a.kB = cv.take<double>((size_t)pc * M);
+                a.iA = cv.take<u32>((size_t)pc * M);    a.iB = cv.take<u32>((size_t)pc * M);
+                a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
+                a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
+                a.split = cv.take<i64>((size_t)pc);
+                {
+                    const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((N + kSeg - 1) / kSeg + 1);
+                    a.rec = cv.take<double>((size_t)pc * 2 * cc * ns * kSegRec);
+                    a.rec2 = cv.take<double>((size_t)pc * 2 * cc * ns * 64 * kMoreBlocks);
+                    a.chstate = cv.take<double>((size_t)pc * 2 * cc * kChState);
+                    a.more = cv.take<unsigned>((size_t)pc * 2);
+                    a.state = cv.take<double>((size_t)pc * 2 * 4);
+                }
+                a.nstage = N > 0 ? N : 1;
+                a.samp = cv.take<double>((size_t)pc * wp.ntiles * 64);
+                a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)wp.ntiles);
+                a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
+                a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
+                a.rank_b = a.rank_t = nullptr;
+                a.do_diag = do_diag;
+                if (ingest) {
+                    double* X = cv.take<double>((size_t)pc * M);
+                    const int r2 = (dtype == MCR_F64) ? launch_ingest<double>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0)
+                                                      : launch_ingest<float>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0);
+                    if (r2) return r2;
+                    a.X = X;
+                } else {
+                    a.X = reinterpret_cast<const double*>(draws_dev) + p0 * M;
+                }
+                const size_t res_off = (size_t)R * (size_t)p0;
+                a.d_res = s.d_res + res_off;
+                const int r3 = run_pipeline(ctx, a);
+                if (r3) return r3;
+                s.chunks.push_back(Chunk{p0, pc, res_off});
             }
-            a.nstage = N > 0 ? N : 1;
-            a.samp = cv.take<double>((size_t)pc * wp.ntiles * 64);
-            a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)wp.ntiles);
-            a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
-            a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
-            a.rank_b = a.rank_t = nullptr;
-            a.do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
-                        out->lag_bulk || out->lag_tail;
-            if (ingest) {
-                double* X = cv.take<double>((size_t)pc * M);
-                rc = (dtype == MCR_F64) ? launch_ingest<double>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0)
-                                        : launch_ingest<float>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0);
-                if (rc) return rc;
-                a.X = X;
-            } else {
-                a.X = reinterpret_cast<const double*>(draws_dev) + p0 * M;
+            HIP_TRY(ctx, hipMemcpyAsync(s.h_res, s.d_res, sizeof(double) * (size_t)R * (size_t)P, hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            return MCR_OK;
+        };
+        if (ctx->graph_on && !ctx->prof) {
+            std::vector<uint64_t> key = {(uint64_t)(uintptr_t)draws_dev, (uint64_t)dtype, (uint64_t)C, (uint64_t)N,
+                                         (uint64_t)P, (uint64_t)sc, (uint64_t)sn, (uint64_t)sp, (uint64_t)nq,
+                                         (uint64_t)si, (uint64_t)do_diag, (uint64_t)(uintptr_t)ctx->ws,
+                                         (uint64_t)(uintptr_t)s.d_res, (uint64_t)(uintptr_t)s.d_off,
+                                         (uint64_t)pcmax};
+            for (int k = 0; k < nq; ++k) {
+                uint64_t bits; memcpy(&bits, &q.g[k], 8);
+                key.push_back((uint64_t)q.lo[k]); key.push_back(bits);
             }
-            const size_t res_off = (size_t)R * (size_t)p0;
-            a.d_res = s.d_res + res_off;
-            rc = run_pipeline(ctx, a);
+            GraphEntry* hit = nullptr;
+            for (GraphEntry& g : ctx->graphs) if (g.key == key) { hit = &g; break; }
+            if (!hit) {
+                if (ctx->graphs.size() >= 64) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); drop_graphs(ctx); }
+                HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                rc = issue();
+                hipGraph_t graph = nullptr;
+                const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+                if (ce != hipSuccess) return fail(ctx, MCR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+                GraphEntry ge;
+                ge.key = key;
+                const hipError_t ie = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+                hipGraphDestroy(graph);
+                if (ie != hipSuccess) return fail(ctx, MCR_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+                ge.chunks = s.chunks;
+                ctx->graphs.push_back(std::move(ge));
+                hit = &ctx->graphs.back();
+            }
+            s.chunks = hit->chunks;
+            HIP_TRY(ctx, hipGraphLaunch(hit->exec, ctx->stream));
+        } else {
+            rc = issue();
             if (rc) return rc;
-            s.chunks.push_back(Chunk{p0, pc, res_off});
         }
-        HIP_TRY(ctx, hipMemcpyAsync(s.h_res, s.d_res, sizeof(double) * (size_t)R * (size_t)P, hipMemcpyDeviceToHost,
-                                    ctx->stream));
     }
     s.busy = true;
     ctx->order.push_back(si);
@@ -588,6 +651,7 @@ int mcr_init(int device, mcr_ctx** out)
     size_t mb = 8192;
     if (const char* env = getenv("MCR_WORKSPACE_MB")) { const long v = atol(env); if (v > 0) mb = (size_t)v; }
     ctx->ws_limit = mb << 20;
+    if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
     *out = ctx;
     return MCR_OK;
 }
@@ -598,6 +662,7 @@ void mcr_free(mcr_ctx* ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     prof_resolve(ctx);
+    drop_graphs(ctx);
     for (hipEvent_t e : ctx->free_ev) hipEventDestroy(e);
     for (Slot& s : ctx->slots) {
         if (s.d_res) hipFree(s.d_res);

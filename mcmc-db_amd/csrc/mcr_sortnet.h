@@ -1,0 +1,17 @@
+/* mcr_sortnet.h -- 16-input sorting network, 60 compare-exchanges in 10 layers.
+ * Plain C so that the host-side test (tests/test_host_cpu.py) can verify it exhaustively with the
+ * 0-1 principle (all 65536 binary inputs).  X(a, b) = compare-exchange positions a < b. */
+#ifndef MCR_SORTNET_H
+#define MCR_SORTNET_H
+#define MCR_NET16(X)                                                                       \
+    X(0, 13) X(1, 12) X(2, 15) X(3, 14) X(4, 8) X(5, 6) X(7, 11) X(9, 10)                 \
+    X(0, 5) X(1, 7) X(2, 9) X(3, 4) X(6, 13) X(8, 14) X(10, 15) X(11, 12)                 \
+    X(0, 1) X(2, 3) X(4, 5) X(6, 8) X(7, 9) X(10, 11) X(12, 13) X(14, 15)                 \
+    X(0, 2) X(1, 3) X(4, 10) X(5, 11) X(6, 7) X(8, 9) X(12, 14) X(13, 15)                 \
+    X(1, 2) X(3, 12) X(4, 6) X(5, 7) X(8, 10) X(9, 11) X(13, 14)                          \
+    X(1, 4) X(2, 6) X(5, 8) X(7, 10) X(9, 13) X(11, 14)                                   \
+    X(2, 4) X(3, 6) X(9, 12) X(11, 13)                                                    \
+    X(3, 5) X(6, 8) X(7, 9) X(10, 12)                                                     \
+    X(3, 4) X(5, 6) X(7, 8) X(9, 10) X(11, 12)                                            \
+    X(6, 7) X(8, 9)
+#endif
