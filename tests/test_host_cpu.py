@@ -169,3 +169,32 @@ def test_gather_records_gloo_world2(tmp_path):
     assert a[4, shard.RECORD_FIELDS.index("q50")] == 2.5 and a[4, shard.RECORD_FIELDS.index("n_draws")] == 1000
     # single-process path is the identity (sorted)
     assert np.array_equal(shard.gather_records(a[::-1]), a)
+
+
+def test_sorting_network_is_a_sorting_network(tmp_path):
+    """0-1 principle: the 16-input network of csrc/mcr_sortnet.h sorts all 65536 binary inputs."""
+    import subprocess
+    src = tmp_path / "check.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "mcr_sortnet.h"
+#define X(a, b) {a, b},
+static const int net[][2] = { MCR_NET16(X) };
+int main(void) {
+    const int n = (int)(sizeof(net) / sizeof(net[0]));
+    long bad = 0;
+    for (unsigned m = 0; m < 65536u; ++m) {
+        int v[16];
+        for (int i = 0; i < 16; ++i) v[i] = (m >> i) & 1;
+        for (int c = 0; c < n; ++c) { int a = net[c][0], b = net[c][1]; if (a >= b) return 3;
+            if (v[b] < v[a]) { int t = v[a]; v[a] = v[b]; v[b] = t; } }
+        for (int i = 0; i < 15; ++i) if (v[i] > v[i + 1]) { ++bad; break; }
+    }
+    printf("%d %ld\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "check"
+    subprocess.run(["gcc", "-O2", "-I", str(ROOT / "mcmc-db_amd" / "csrc"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["60", "0"]

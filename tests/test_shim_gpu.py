@@ -212,3 +212,40 @@ def test_summarize_models_single_process(oracle):
             for k in ("std", "rhat", "ess_bulk", "ess_tail"):
                 assert r[F.index(k)] == pytest.approx(exp[k][p], rel=1e-9)
             row += 1
+
+
+def test_corpus_shaped_batch_matches_per_model(oracle):
+    """BASELINE config 2 geometry: 57 model shapes; batched pipelines == per-model pipelines, and the
+    six real fixture models inside the batch still reproduce their packaged meta.json goldens."""
+    from conftest import MODEL_NAMES
+    from mcmc_ref_hip import _ffi, corpus, shard
+    real = {}
+    recs = {}
+    for name in MODEL_NAMES:
+        draws, params, rec = load_model(name)
+        real[name], recs[name] = draws, (params, rec)
+    models = corpus.synthetic_corpus(seed=99, real_models=real)
+    assert len(models) == 57 and sum(a.shape[0] for _, a in models) == 460
+    ctx = _ffi.default_context()
+    pairs = [(a, "pcn") for _, a in models]
+    batched = shard.summarize_models(ctx, pairs, batch=True)
+    single = shard.summarize_models(ctx, pairs, batch=False)
+    assert batched.shape == (460, shard.RECORD_DOUBLES)
+    assert np.array_equal(batched, single, equal_nan=True)
+    F = shard.RECORD_FIELDS
+    names = [n for n, _ in models]
+    for name, (params, rec) in recs.items():
+        mi = names.index(name)
+        rows = batched[batched[:, F.index("model_idx")] == mi]
+        assert rows.shape[0] == len(params)
+        for j, pn in enumerate(params):
+            for k in ("rhat", "ess_bulk", "ess_tail"):
+                assert rows[j, F.index(k)] == pytest.approx(rec["meta_diagnostics"][pn][k], rel=1e-6)
+    # spot-check three synthetic models against the oracle
+    for mi in (0, 20, 41):
+        if names[mi] in recs:
+            continue
+        exp = oracle.summarize(models[mi][1], "pcn")
+        rows = batched[batched[:, F.index("model_idx")] == mi]
+        assert np.array_equal(rows[:, F.index("lag_bulk")], exp["lag_bulk"])
+        assert np.allclose(rows[:, F.index("ess_tail")], exp["ess_tail"], rtol=1e-9)
