@@ -7,7 +7,12 @@ parameter), `_checks` (:164-172) and `_enforce_checks` (:175-178).
 """
 from __future__ import annotations
 
+import json
+import zipfile
 from collections.abc import Iterable
+from dataclasses import dataclass
+from datetime import date
+from pathlib import Path
 from typing import Any
 
 import numpy as np
@@ -89,6 +94,32 @@ def _compute_diagnostics(table: Any, params: Iterable[str], *, min_chains: int =
     return diag
 
 
+def summarize_table(table: Any, params: Iterable[str], *, min_chains: int = 4, context=None,
+                    quantiles=(0.05, 0.5, 0.95)) -> dict[str, dict[str, float]]:
+    """Backend.stats + diagnostics of every parameter of a long table from ONE kernel pipeline."""
+    params = list(params)
+    if not params:
+        return {}
+    x, counts = table_to_tensor(table, params)
+    C = len(counts)
+    if C == 0 or not np.all(counts == counts[0]):
+        raise ValueError("summarize_table needs chains of equal length")
+    ctx = context or _ffi.default_context()
+    qs = list(quantiles)
+    try:
+        r = ctx.summarize(x.reshape(len(params), C, int(counts[0])), "pcn", min_chains=min_chains, quantiles=qs)
+    except _ffi.McrError as exc:
+        raise ValueError(exc.message) from exc
+    out: dict[str, dict[str, float]] = {}
+    for i, p in enumerate(params):
+        e = {"mean": float(r["mean"][i]), "std": float(r["std"][i])}
+        for q, v in zip(qs, r["q"][i], strict=False):
+            e[f"q{int(q * 100)}"] = float(v)
+        e.update(rhat=float(r["rhat"][i]), ess_bulk=float(r["ess_bulk"][i]), ess_tail=float(r["ess_tail"][i]))
+        out[p] = e
+    return out
+
+
 def _checks(n_chains: int, n_draws: int, diag: dict[str, dict[str, float]]) -> dict[str, bool]:
     ess_ok = all(values.get("ess_bulk", 0.0) > 400 for values in diag.values())
     rhat_ok = all(values.get("rhat", 1.0) < 1.01 for values in diag.values())
@@ -104,3 +135,78 @@ def _enforce_checks(checks: dict[str, bool]) -> None:
     failures = [name for name, ok in checks.items() if not ok]
     if failures:
         raise ValueError(f"quality checks failed: {', '.join(failures)}")
+
+
+# ---- file conversion (reference src/mcmc_ref/convert.py:26-120): JSON-zip / CSV -> Parquet + meta ----
+@dataclass(frozen=True)
+class ConvertResult:
+    draws_path: Path
+    meta_path: Path
+    meta: dict
+
+
+def _read_json_zip(path: Path):
+    """Chain-list JSON-zip: [ {param: [draws...]}, ... ] (one dict per chain) -> long Arrow table."""
+    import pyarrow as pa
+    with zipfile.ZipFile(path) as zf:
+        payload = json.loads(zf.read(zf.namelist()[0]))
+    if not isinstance(payload, list) or not payload:
+        raise ValueError("json-zip payload must be a non-empty list of chains")
+    params = sorted(payload[0].keys())
+    n_draws = len(next(iter(payload[0].values())))
+    n_chains = len(payload)
+    cols = {"chain": np.repeat(np.arange(n_chains, dtype=np.int64), n_draws),
+            "draw": np.tile(np.arange(n_draws, dtype=np.int64), n_chains)}
+    for p in params:
+        cols[p] = np.concatenate([np.asarray(ch[p][:n_draws], dtype=np.float64) for ch in payload]) \
+            if n_draws else np.empty(0)
+    return pa.table(cols)
+
+
+def _read_input(path: Path):
+    import pyarrow.csv as pacsv
+    if path.suffix == ".csv":
+        return pacsv.read_csv(path)
+    if path.suffixes[-2:] == [".json", ".zip"]:
+        return _read_json_zip(path)
+    raise ValueError(f"Unsupported input format: {path}")
+
+
+def _ensure_chain_draw(table):
+    """Add the missing bookkeeping columns like the reference does (convert.py:105-120): a missing
+    `draw` is the row number, a missing `chain` is chain 0 (int32, appended after the parameters)."""
+    import pyarrow as pa
+    cols = set(table.column_names)
+    n = table.num_rows
+    chain = pa.array(np.zeros(n, dtype=np.int32))
+    draw = pa.array(np.arange(n, dtype=np.int32))
+    if "chain" in cols and "draw" in cols:
+        return table
+    if "chain" in cols:
+        return table.append_column("draw", draw)
+    if "draw" in cols:
+        return table.append_column("chain", chain)
+    return table.append_column("chain", chain).append_column("draw", draw)
+
+
+def convert_file(input_path: Path, name: str, out_draws_dir: Path, out_meta_dir: Path, force: bool = False,
+                 source: str = "converted") -> ConvertResult:
+    """Same contract as the reference's convert_file: diagnostics of every parameter (one GPU pipeline
+    per file), quality checks (raise ValueError("quality checks failed: ...") unless `force`), then
+    `<name>.draws.parquet` and `<name>.meta.json` (sorted keys, indent 2)."""
+    import pyarrow.parquet as pq
+    input_path, out_draws_dir, out_meta_dir = Path(input_path), Path(out_draws_dir), Path(out_meta_dir)
+    table = _ensure_chain_draw(_read_input(input_path))
+    params = [c for c in table.column_names if c not in {"chain", "draw"}]
+    n_chains, n_draws = _count_chains_draws(table)
+    diag = _compute_diagnostics(table, params, min_chains=1 if force else 4)
+    checks = _checks(n_chains, n_draws, diag)
+    if not force:
+        _enforce_checks(checks)
+    meta = {"model": name, "parameters": params, "n_chains": n_chains, "n_draws_per_chain": n_draws,
+            "diagnostics": diag, "generated_date": date.today().isoformat(), "checks": checks, "source": source}
+    draws_path = out_draws_dir / f"{name}.draws.parquet"
+    meta_path = out_meta_dir / f"{name}.meta.json"
+    pq.write_table(table, draws_path)
+    meta_path.write_text(json.dumps(meta, indent=2, sort_keys=True))
+    return ConvertResult(draws_path=draws_path, meta_path=meta_path, meta=meta)

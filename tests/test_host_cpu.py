@@ -4,6 +4,7 @@ gloo with world_size 2."""
 from __future__ import annotations
 
 import ctypes
+import json
 import os
 import re
 import sys
@@ -198,3 +199,51 @@ int main(void) {
     subprocess.run(["gcc", "-O2", "-I", str(ROOT / "mcmc-db_amd" / "csrc"), "-o", str(exe), str(src)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out == ["60", "0"]
+
+
+def test_store_layout_and_precedence(tmp_path):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from mcmc_ref_hip.store import DataStore
+    pkg, loc = tmp_path / "pkg", tmp_path / "loc"
+    for root, val in ((pkg, 1.0), (loc, 2.0)):
+        (root / "draws").mkdir(parents=True); (root / "meta").mkdir(); (root / "stan_data").mkdir()
+        pq.write_table(pa.table({"chain": [0, 0, 1, 1], "draw": [0, 1, 0, 1], "mu": [val] * 4, "tau": [3.0] * 4}),
+                       root / "draws" / "m.draws.parquet")
+        (root / "meta" / "m.meta.json").write_text(json.dumps({"who": root.name}))
+    (loc / "stan_models").mkdir()
+    (loc / "stan_models" / "m.stan").write_text("parameters { real mu; }")
+    pq.write_table(pa.table({"chain": [0], "draw": [0], "x": [1.0]}), loc / "draws" / "only_local.draws.parquet")
+    st = DataStore(local_root=loc, packaged_root=pkg)
+    assert st.list_models() == ["m", "only_local"]
+    assert st.read_meta("m") == {"who": "pkg"}                       # packaged root wins
+    assert st.resolve_draws_path("only_local").parent.parent == loc
+    assert st.read_stan_code("m").startswith("parameters")
+    with pytest.raises(FileNotFoundError, match="stan data not found for model: m"):
+        st.read_stan_data("m")
+    with pytest.raises(FileNotFoundError, match="draws not found for model: zzz"):
+        st.resolve_draws_path("zzz")
+    t = st.open_draws("m", params=["tau"], chains=[1]).read_all()
+    assert t.column_names == ["chain", "draw", "tau"] and t.num_rows == 2
+    assert st.open_draws("m").read_all().column("mu").to_pylist() == [1.0] * 4
+    assert DataStore(local_root=tmp_path / "none", packaged_root=tmp_path / "none2").list_models() == []
+
+
+def test_convert_readers_cpu(tmp_path):
+    import zipfile
+    import pyarrow as pa
+    from mcmc_ref_hip import convert
+    jz = tmp_path / "a.json.zip"
+    with zipfile.ZipFile(jz, "w") as zf:
+        zf.writestr("a.json", json.dumps([{"b": [1.0, 2.0], "a": [3.0, 4.0]}, {"b": [5.0, 6.0], "a": [7.0, 8.0]}]))
+    t = convert._read_json_zip(jz)
+    assert t.column_names == ["chain", "draw", "a", "b"]
+    assert t.column("chain").to_pylist() == [0, 0, 1, 1] and t.column("a").to_pylist() == [3.0, 4.0, 7.0, 8.0]
+    with zipfile.ZipFile(jz, "w") as zf:
+        zf.writestr("a.json", json.dumps({"not": "a list"}))
+    with pytest.raises(ValueError, match="non-empty list of chains"):
+        convert._read_json_zip(jz)
+    bare = convert._ensure_chain_draw(pa.table({"x": [1.0, 2.0, 3.0]}))
+    assert bare.column_names == ["x", "chain", "draw"] and bare.column("draw").to_pylist() == [0, 1, 2]
+    only_chain = convert._ensure_chain_draw(pa.table({"chain": [0, 0], "x": [1.0, 2.0]}))
+    assert only_chain.column_names == ["chain", "x", "draw"]
