@@ -238,3 +238,37 @@ def test_workspace_chunking_gives_identical_results(ctx):
         ctx._check(ctx.lib.mcr_set_workspace_limit(ctx.handle, 8 << 30))
     for k in full:
         assert np.array_equal(full[k], chunked[k], equal_nan=True), k
+
+
+def test_long_chains_merge_pass_path(ctx, oracle):
+    """M = 4 x 70000 = 280k pooled draws: beyond the bucket path (69 tiles), so the pairwise merge
+    passes, the standalone rank kernel and 35 autocovariance segments per chain are exercised
+    (the geometry of BASELINE config 4, N = 100000)."""
+    from mcmc_ref_hip import synth
+    x = synth.c1_model(4, 70000, 3, seed=21)
+    x[2] = np.round(x[2], 1)                       # heavy ties across tile and block edges
+    got = ctx.summarize(x, "pcn")
+    exp = oracle.summarize(x, "pcn")
+    check_summary(got, exp, what="long")
+    f32 = x[:2].astype(np.float32)
+    cnp = np.ascontiguousarray(np.transpose(f32, (1, 2, 0)))          # [C][N][P] f32 through k_ingest_transpose
+    check_summary(ctx.summarize(cnp, "cnp"), oracle.summarize(cnp, "cnp"), what="long-f32-cnp")
+
+
+def test_sticky_chains_continuation_paths(ctx, oracle):
+    """AR(1) with phi = 0.995: the first negative rho lies hundreds of lags out, so the flagged
+    continuation (lags 64..255) and the direct loop beyond it decide the truncation lag."""
+    rng = np.random.default_rng(17)
+    C, N = 4, 6000
+    x = np.empty((2, C, N))
+    for p, phi in enumerate((0.97, 0.995)):
+        e = rng.normal(size=(C, N))
+        for c in range(C):
+            y = np.empty(N); y[0] = e[c, 0]
+            for t in range(1, N):
+                y[t] = phi * y[t - 1] + np.sqrt(1 - phi * phi) * e[c, t]
+            x[p, c] = y
+    got = ctx.summarize(x, "pcn")
+    exp = oracle.summarize(x, "pcn")
+    assert int(exp["lag_bulk"].max()) > 255, exp["lag_bulk"]
+    check_summary(got, exp, what="sticky")
