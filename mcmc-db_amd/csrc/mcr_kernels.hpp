@@ -15,6 +15,7 @@
 // (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
 #pragma once
 #include "mcr_device.hpp"
+#include "mcr_sortnet.h"
 
 namespace mcr {
 
@@ -208,19 +209,22 @@ __global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, c
 // Also emits the shifted moment partials of its tile (so the draws are read from HBM once).
 // Partial tiles are padded with +inf (draws are finite or the call fails with MCR_ENONFINITE).
 // ------------------------------------------------------------------------------------------------
+// 16 registers per lane, fully static 60-comparator network (mcr_sortnet.h): every index is a
+// compile-time constant, so the keys stay in VGPRs (a loop-carried index here makes hipcc emulate
+// dynamic register indexing with 16-way select chains: 10x the instructions).
 template <int VT>
 __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 {
-#pragma unroll
-    for (int round = 0; round < VT; ++round) {
-#pragma unroll
-        for (int i = (round & 1); i + 1 < VT; i += 2) {
-            const bool sw = k[i + 1] < k[i];
-            const double a = sw ? k[i + 1] : k[i], b = sw ? k[i] : k[i + 1];
-            const u32 ia = sw ? ix[i + 1] : ix[i], ib = sw ? ix[i] : ix[i + 1];
-            k[i] = a; k[i + 1] = b; ix[i] = ia; ix[i + 1] = ib;
-        }
+    static_assert(VT == 16, "the sorting network is for 16 items per lane");
+#define MCR_CE(a, b)                                                        \
+    {                                                                       \
+        const bool sw = k[b] < k[a];                                        \
+        const double lo = sw ? k[b] : k[a], hi = sw ? k[a] : k[b];          \
+        const u32 ilo = sw ? ix[b] : ix[a], ihi = sw ? ix[a] : ix[b];       \
+        k[a] = lo; k[b] = hi; ix[a] = ilo; ix[b] = ihi;                     \
     }
+    MCR_NET16(MCR_CE)
+#undef MCR_CE
 }
 
 // Serial merge of up to VT outputs from LDS runs A = skey[pos(a0 + .)] (na items) and
