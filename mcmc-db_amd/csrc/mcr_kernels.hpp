@@ -641,8 +641,15 @@ __global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ ke
             const int ts = splt[b];
             if (t == ts) c = (u32)(splp[b] + 1);
             else {
+                // the tile's own samples (in LDS) bracket the answer to a 64-draw window
+                const double* sa = sv + t * SPT;
+                int slo = 0, shi = SPT;
+                if (t < ts) { while (slo < shi) { const int m = (slo + shi) >> 1; if (!(v < sa[m])) slo = m + 1; else shi = m; } }
+                else        { while (slo < shi) { const int m = (slo + shi) >> 1; if (sa[m] < v) slo = m + 1; else shi = m; } }
                 const double* a = kp + tbase;
-                int lo = 0, hi = cnt;
+                int lo = 64 * slo, hi = 64 * slo + 63;        // sample j sits at position 64 j + 63
+                if (lo > cnt) lo = cnt;
+                if (hi > cnt) hi = cnt;
                 if (t < ts) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
                 else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
                 c = (u32)lo;
@@ -706,8 +713,10 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     const i64 obase = boff[p * (B + 1) + b];
     // gather pieces (+inf pads)
     for (int e = tid; e < padded; e += NT) {
-        int t = 0;
-        while (t + 1 < k && e >= sst[t + 1]) ++t;
+        int t = 0;   // last piece whose padded start is <= e (starts are non-decreasing)
+#pragma unroll
+        for (int step = 8; step > 0; step >>= 1)
+            if (t + step < k && e >= sst[t + step]) t += step;
         const int o = e - sst[t];
         double v = INFINITY; u32 id = 0xFFFFFFFFu;
         if (o < spl[t]) { const i64 g = (i64)t * T + sps[t] + o; v = kp[g]; id = ip[g]; }
