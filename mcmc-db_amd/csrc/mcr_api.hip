@@ -292,7 +292,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
     bool ranked = false;
     if (bucket) {
         // 2a. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
-        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(256), 0, (const double*)kin, (const double*)a.samp, M,
+        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(1024), 0, (const double*)kin, (const double*)a.samp, M,
                (int)a.ntiles, a.bk_B, a.bk_D, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,

@@ -593,12 +593,13 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxBucketTiles = 16;
 
-__global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ keys,
-                                                   const double* __restrict__ samp, i64 M, int k, int B,
-                                                   int D, u32* __restrict__ cut, u32* __restrict__ boff)
+__global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ keys,
+                                                    const double* __restrict__ samp, i64 M, int k, int B,
+                                                    int D, u32* __restrict__ cut, u32* __restrict__ boff)
 {
-    constexpr int T = 4096, SPT = 64;
+    constexpr int T = 4096, SPT = 64, NTS = 1024;
     __shared__ double sv[kMaxBucketTiles * SPT];
+    __shared__ int srank[kMaxBucketTiles * SPT];
     __shared__ double splv[64];
     __shared__ int splt[64], splp[64];
     __shared__ u32 scut[65 * kMaxBucketTiles];
@@ -606,30 +607,33 @@ __global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ ke
     const i64 p = blockIdx.x;
     const double* kp = keys + p * M;
     const int S = k * SPT;
-    for (int i = tid; i < S; i += 256) sv[i] = samp[p * S + i];
+    for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; srank[i] = i % SPT; }
     __syncthreads();
-    // pooled rank of every finite sample: own index + samples of the other tiles below it
-    for (int i = tid; i < S; i += 256) {
+    // pooled rank of every finite sample = own index + samples of every other tile below it;
+    // one (sample, other tile) pair per thread step
+    for (int q = tid; q < S * k; q += NTS) {
+        const int i = q / k, t2 = q % k;
         const double v = sv[i];
-        if (!(v < INFINITY)) continue;
-        const int t = i / SPT, j = i % SPT;
-        int r = j;
-        for (int t2 = 0; t2 < k; ++t2) {
-            if (t2 == t) continue;
-            const double* a = sv + t2 * SPT;
-            int lo = 0, hi = SPT;  // count of samples of tile t2 that sort before (v, t, j)
-            if (t2 < t) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
-            else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
-            r += lo;
-        }
+        const int t = i / SPT;
+        if (t2 == t || !(v < INFINITY)) continue;
+        const double* a = sv + t2 * SPT;
+        int lo = 0, hi = SPT;  // count of samples of tile t2 that sort before (v, t, j)
+        if (t2 < t) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
+        else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
+        if (lo) atomicAdd(&srank[i], lo);
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += NTS) {
+        if (!(sv[i] < INFINITY)) continue;
+        const int r = srank[i];
         if ((r + 1) % D == 0) {
             const int b = (r + 1) / D;
-            if (b >= 1 && b < B) { splv[b] = v; splt[b] = t; splp[b] = 64 * j + 63; }
+            if (b >= 1 && b < B) { splv[b] = sv[i]; splt[b] = i / SPT; splp[b] = 64 * (i % SPT) + 63; }
         }
     }
     __syncthreads();
     // cuts: position in tile t where bucket b starts
-    for (int q = tid; q < (B + 1) * k; q += 256) {
+    for (int q = tid; q < (B + 1) * k; q += NTS) {
         const int b = q / k, t = q % k;
         const i64 tbase = (i64)t * T;
         const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256) void k_splitters(const double* __restrict__ ke
         cut[(p * (B + 1) + b) * k + t] = c;
     }
     __syncthreads();
-    for (int b = tid; b <= B; b += 256) {
+    for (int b = tid; b <= B; b += NTS) {
         u32 o = 0;
         for (int t = 0; t < k; ++t) o += scut[b * k + t];
         boff[p * (B + 1) + b] = o;
