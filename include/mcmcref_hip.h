@@ -153,6 +153,18 @@ int mcr_moments_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, i
 int mcr_compare(mcr_ctx* ctx, const double* ref, const double* actual, int64_t n, double tol,
                 double* rel_error, uint8_t* passed);
 
+/* ---- extensions (named in the north star, ABSENT from the reference: parity unpinned by it) ----- */
+/* Two-sample Kolmogorov-Smirnov statistic and Wasserstein-1 distance per parameter between the
+ * reference draws ref[P][Mr] and the actual draws act[P][Ma] (host pointers, row-major, finite).
+ * Definitions follow scipy.stats.ks_2samp(...).statistic and scipy.stats.wasserstein_distance:
+ * both samples are sorted on the device and compared in one merge-path pass.  SURVEY.md rows X1, X2. */
+int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* act, int64_t Ma, int64_t P,
+                   double* ks, double* w1);
+/* Population covariance matrix (ddof = 0, like compare.py:63) of P parameters over M pooled draws,
+ * draws[P][M] host row-major -> cov[P][P].  The one dense contraction of the path: fp64 MFMA
+ * (v_mfma_f64_16x16x4f64), split over the draw axis.  numpy.cov(x, ddof=0).  SURVEY.md row X3. */
+int mcr_covariance(mcr_ctx* ctx, const double* draws, int64_t M, int64_t P, double* cov);
+
 /* ---- measurement ------------------------------------------------------------------- */
 /* When on, every kernel launch is bracketed by HIP events on the ctx stream. */
 int mcr_profile_enable(mcr_ctx* ctx, int on);

@@ -14,6 +14,7 @@
 
 #include "mcr_kernels.hpp"
 #include "mcr_diag.hpp"
+#include "mcr_ext.hpp"
 
 using namespace mcr;
 
@@ -27,12 +28,12 @@ constexpr int kMaxGridY = 65535;
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
-    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg"};
+    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -277,8 +278,9 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     return MCR_OK;
 }
 
-// The whole per-chunk pipeline on ctx->stream.  M >= 1, pc >= 1.
-int run_pipeline(mcr_ctx* ctx, PipeIn& a)
+// Tile sort + (bucket partition | merge passes): leaves the pooled ascending (key, idx) order of every
+// parameter in *kin / *iin (one of the two ping-pong sets) and, on the bucket path with do_diag, z_bulk.
+int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** kout_o, u32** iout_o, bool* ranked_o)
 {
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
@@ -310,6 +312,23 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
             std::swap(kin, kout);
             std::swap(iin, iout);
         }
+    }
+    *kin_o = kin; *iin_o = iin; *kout_o = kout; *iout_o = iout; *ranked_o = ranked;
+    return MCR_OK;
+}
+
+// The whole per-chunk pipeline on ctx->stream.  M >= 1, pc >= 1.
+int run_pipeline(mcr_ctx* ctx, PipeIn& a)
+{
+    const i64 M = a.M, pc = a.pc;
+    const unsigned py = (unsigned)pc;
+    const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
+    double *kin, *kout;
+    u32 *iin, *iout;
+    bool ranked;
+    {
+        const int rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
+        if (rc) return rc;
     }
     // 3. order statistics
     LAUNCH(ctx, K_ORDER_STATS, k_order_stats, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
@@ -932,6 +951,124 @@ int mcr_compare(mcr_ctx* ctx, const double* ref, const double* actual, int64_t n
            (const double*)d_act, (i64)n, tol, d_rel, d_ok);
     HIP_TRY(ctx, hipMemcpyAsync(rel_error, d_rel, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(passed, d_ok, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
+// Sort-only carve of the workspace for P parameters of M draws each (no diagnostics buffers).
+static int carve_sort(mcr_ctx* ctx, Carve& cv, i64 M, i64 P, PipeIn& a)
+{
+    const WsPlan wp = plan_ws(M, 1, false, false, 1);
+    a = PipeIn{};
+    a.M = M; a.pc = P; a.C = 1; a.ntiles = wp.ntiles; a.do_diag = false;
+    a.kA = cv.take<double>((size_t)P * M); a.kB = cv.take<double>((size_t)P * M);
+    a.iA = cv.take<u32>((size_t)P * M);    a.iB = cv.take<u32>((size_t)P * M);
+    a.part = cv.take<double>((size_t)P * wp.ntiles * 4);
+    a.samp = cv.take<double>((size_t)P * wp.ntiles * 64);
+    a.cut = cv.take<u32>((size_t)P * (wp.bk_B + 1) * (size_t)wp.ntiles);
+    a.boff = cv.take<u32>((size_t)P * (wp.bk_B + 1));
+    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
+    return MCR_OK;
+}
+
+int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* act, int64_t Ma, int64_t P,
+                   double* ks, double* w1)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (P < 0 || Mr < 1 || Ma < 1 || (P > 0 && (!ref || !act || !ks || !w1)))
+        return fail(ctx, MCR_EINVAL, "bad argument (both samples need at least one draw)");
+    if (P == 0) return MCR_OK;
+    if (P > kMaxGridY) return fail(ctx, MCR_EINVAL, "P > %d", kMaxGridY);
+    if (Mr >= (i64)0xFFFFFFFFll || Ma >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "sample too long");
+    if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_two_sample with summaries in flight");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const i64 Mx = Mr > Ma ? Mr : Ma;
+    const int nblk = (int)((Mr + Ma + kTile - 1) / kTile);
+    const size_t need = (size_t)P * (size_t)Mx * (8 + 4) * 2 + (size_t)P * (size_t)(Mr + Ma) * 8 * 2 +
+                        (size_t)P * ((size_t)((Mx + kTile - 1) / kTile) * (32 + 512 + 4 * 80) + (size_t)nblk * 16 + 64) +
+                        64 * 256;
+    int rc = ensure_ws(ctx, need);
+    if (rc) return rc;
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    double* Xr = cv.take<double>((size_t)P * Mr);
+    double* Xa = cv.take<double>((size_t)P * Ma);
+    double* Sr = cv.take<double>((size_t)P * Mr);
+    double* part = cv.take<double>((size_t)P * nblk * 2);
+    double* d_ks = cv.take<double>((size_t)P);
+    double* d_w = cv.take<double>((size_t)P);
+    double* bad = cv.take<double>((size_t)P * 2);
+    const size_t base = cv.off;
+    HIP_TRY(ctx, hipMemcpyAsync(Xr, ref, sizeof(double) * (size_t)P * Mr, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(Xa, act, sizeof(double) * (size_t)P * Ma, hipMemcpyHostToDevice, ctx->stream));
+    double *kin, *kout; u32 *iin, *iout; bool ranked;
+    PipeIn a;
+    {   // ascending order of the reference sample, parked in Sr
+        Carve c2{reinterpret_cast<char*>(ctx->ws), base};
+        carve_sort(ctx, c2, Mr, P, a);
+        a.X = Xr;
+        rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(Sr, kin, sizeof(double) * (size_t)P * Mr, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    {   // ascending order of the actual sample, then one merge-path pass over both
+        Carve c2{reinterpret_cast<char*>(ctx->ws), base};
+        carve_sort(ctx, c2, Ma, P, a);
+        a.X = Xa;
+        rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
+        if (rc) return rc;
+    }
+    LAUNCH(ctx, K_TWO_SAMPLE, (k_two_sample<256, 16>), dim3((unsigned)nblk, (unsigned)P), dim3(256), 0,
+           (const double*)Sr, (i64)Mr, (const double*)kin, (i64)Ma, part, nblk);
+    LAUNCH(ctx, K_TWO_SAMPLE, k_two_sample_final, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+           (const double*)part, nblk, (i64)P, d_ks, d_w);
+    HIP_TRY(ctx, hipMemcpyAsync(ks, d_ks, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(w1, d_w, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    (void)bad;
+    for (i64 p = 0; p < P; ++p)
+        if (!(ks[p] == ks[p]) || !(w1[p] == w1[p]) || std::isinf(w1[p]))
+            return fail(ctx, MCR_ENONFINITE, "draws contain non-finite values");
+    return MCR_OK;
+}
+
+int mcr_covariance(mcr_ctx* ctx, const double* draws, int64_t M, int64_t P, double* cov)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (P < 0 || M < 1 || (P > 0 && (!draws || !cov))) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (P == 0) return MCR_OK;
+    if (P > 4096) return fail(ctx, MCR_EINVAL, "P > 4096 not supported by mcr_covariance");
+    if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_covariance with summaries in flight");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int tiles = (int)((P + 15) / 16);
+    const i64 P16 = (i64)tiles * 16;
+    int ksplit = (int)((2048 + (i64)tiles * tiles - 1) / ((i64)tiles * tiles));   // >= ~2048 waves in flight
+    const i64 maxsplit = (M + 255) / 256;
+    if (ksplit > maxsplit) ksplit = (int)maxsplit;
+    if (ksplit < 1) ksplit = 1;
+    i64 kchunk = (M + ksplit - 1) / ksplit;
+    kchunk = (kchunk + 3) / 4 * 4;
+    ksplit = (int)((M + kchunk - 1) / kchunk);
+    const int S = 8;
+    const size_t need = (size_t)P * M * 8 + (size_t)ksplit * P16 * P16 * 8 + (size_t)P * P * 8 + (size_t)P * (S * 32 + 16) + 16 * 256;
+    int rc = ensure_ws(ctx, need);
+    if (rc) return rc;
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    double* X = cv.take<double>((size_t)P * M);
+    double* partial = cv.take<double>((size_t)ksplit * P16 * P16);
+    double* d_cov = cv.take<double>((size_t)P * P);
+    double* mpart = cv.take<double>((size_t)P * S * 4);
+    double* d_mean = cv.take<double>((size_t)P);
+    double* d_std = cv.take<double>((size_t)P);
+    HIP_TRY(ctx, hipMemcpyAsync(X, draws, sizeof(double) * (size_t)P * M, hipMemcpyHostToDevice, ctx->stream));
+    rc = moments_impl<double>(ctx, X, 1, M, P, M, 1, M, d_mean, d_std, mpart, (M >= 8 * 2048) ? S : 1, true);
+    if (rc) return rc;
+    LAUNCH(ctx, K_COV, k_cov_mfma, dim3((unsigned)(tiles * tiles), (unsigned)ksplit), dim3(64), 0, (const double*)X,
+           (i64)M, (i64)P, tiles, kchunk, partial);
+    LAUNCH(ctx, K_COV, k_cov_final, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, (const double*)partial,
+           ksplit, tiles, (const double*)X, (i64)M, (i64)P, (const double*)d_mean, d_cov);
+    HIP_TRY(ctx, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     prof_resolve(ctx);
     return MCR_OK;

@@ -73,6 +73,8 @@ SYMBOLS = {
     "mcr_basic_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _dp, _dp]),
     "mcr_moments_dev": (C.c_int, [C.c_void_p] + _TENSOR + [_dp, _dp]),
     "mcr_compare": (C.c_int, [C.c_void_p, _dp, _dp, _I64, C.c_double, _dp, C.POINTER(C.c_uint8)]),
+    "mcr_two_sample": (C.c_int, [C.c_void_p, _dp, _I64, _dp, _I64, _I64, _dp, _dp]),
+    "mcr_covariance": (C.c_int, [C.c_void_p, _dp, _I64, _I64, _dp]),
     "mcr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mcr_profile_reset": (C.c_int, [C.c_void_p]),
     "mcr_profile_get": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
@@ -352,6 +354,31 @@ class Context:
         self._check(self.lib.mcr_compare(self.handle, _as_dp(r), _as_dp(a), r.size, float(tol), _as_dp(rel),
                                          ok.ctypes.data_as(C.POINTER(C.c_uint8))))
         return rel[:r.size], ok[:r.size].astype(bool)
+
+    # -- extensions (not in the reference) -------------------------------------------------------------
+    def two_sample(self, ref, actual) -> tuple[np.ndarray, np.ndarray]:
+        """(KS statistic, Wasserstein-1) per parameter; ref [P][Mr], actual [P][Ma] (2-D, finite)."""
+        r = np.ascontiguousarray(ref, dtype=np.float64)
+        a = np.ascontiguousarray(actual, dtype=np.float64)
+        if r.ndim != 2 or a.ndim != 2 or r.shape[0] != a.shape[0]:
+            raise ValueError("ref and actual must be 2-D with the same number of parameters")
+        if not (np.isfinite(r).all() and np.isfinite(a).all()):
+            raise ValueError("draws contain non-finite values")
+        P = r.shape[0]
+        ks, w1 = np.full(max(P, 1), np.nan), np.full(max(P, 1), np.nan)
+        self._check(self.lib.mcr_two_sample(self.handle, _as_dp(r), r.shape[1], _as_dp(a), a.shape[1], P,
+                                            _as_dp(ks), _as_dp(w1)))
+        return ks[:P], w1[:P]
+
+    def covariance(self, draws) -> np.ndarray:
+        """Population covariance (ddof=0) of draws [P][M] -> [P][P] (fp64 MFMA)."""
+        x = np.ascontiguousarray(draws, dtype=np.float64)
+        if x.ndim != 2:
+            raise ValueError("draws must be 2-D [P][M]")
+        P = x.shape[0]
+        cov = np.full((max(P, 1), max(P, 1)), np.nan)
+        self._check(self.lib.mcr_covariance(self.handle, _as_dp(x), x.shape[1], P, _as_dp(cov)))
+        return cov[:P, :P] if P else np.empty((0, 0))
 
     # -- measurement -----------------------------------------------------------------------------
     def profile(self, on: bool):
