@@ -10,9 +10,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "csrc" / "mcr_api.hip"
-DEPS = [SRC, HERE / "csrc" / "mcr_kernels.hpp", HERE / "csrc" / "mcr_device.hpp",
-        HERE / "csrc" / "mcr_diag.hpp", HERE / "csrc" / "mcr_sortnet.h",
-        HERE.parent / "include" / "mcmcref_hip.h"]
+DEPS = sorted((HERE / "csrc").glob("*.h*")) + [SRC, HERE.parent / "include" / "mcmcref_hip.h"]
 OUT = HERE / "lib" / "libmcmcref_hip.so"
 
 

@@ -980,7 +980,8 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
         return fail(ctx, MCR_EINVAL, "bad argument (both samples need at least one draw)");
     if (P == 0) return MCR_OK;
     if (P > kMaxGridY) return fail(ctx, MCR_EINVAL, "P > %d", kMaxGridY);
-    if (Mr >= (i64)0xFFFFFFFFll || Ma >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "sample too long");
+    if (Mr >= (i64)0xFFFFFFFFll || Ma >= (i64)0xFFFFFFFFll || (double)Mr * (double)Ma >= 9007199254740992.0)
+        return fail(ctx, MCR_EINVAL, "samples too long (Mr * Ma must stay below 2^53)");
     if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_two_sample with summaries in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const i64 Mx = Mr > Ma ? Mr : Ma;
@@ -1021,7 +1022,7 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
     LAUNCH(ctx, K_TWO_SAMPLE, (k_two_sample<256, 16>), dim3((unsigned)nblk, (unsigned)P), dim3(256), 0,
            (const double*)Sr, (i64)Mr, (const double*)kin, (i64)Ma, part, nblk);
     LAUNCH(ctx, K_TWO_SAMPLE, k_two_sample_final, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
-           (const double*)part, nblk, (i64)P, d_ks, d_w);
+           (const double*)part, nblk, (i64)P, (double)Mr * (double)Ma, d_ks, d_w);
     HIP_TRY(ctx, hipMemcpyAsync(ks, d_ks, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(w1, d_w, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

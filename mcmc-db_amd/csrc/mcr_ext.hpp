@@ -12,6 +12,8 @@ namespace mcr {
 // pass over the pooled order.  At every pooled position t that ends a run of equal values, with
 // i = #(r <= v_t), j = #(a <= v_t):    D = max |i/Mr - j/Ma|     W1 += |i/Mr - j/Ma| (v_{t+1} - v_t)
 // (scipy: searchsorted(..., side="right") / n on the pooled values; deltas = diff(sorted pooled)).
+// D is formed exactly: max |i*Ma - j*Mr| as an integer, divided once by Mr*Ma (scipy's exact mode rounds
+// its statistic to the same rational).
 // grid (nblk, P); part[(p*nblk + blk)*2 + {0,1}] = block max, block sum.
 // ------------------------------------------------------------------------------------------------
 template <int NT, int VT>
@@ -49,9 +51,8 @@ __global__ __launch_bounds__(NT) void k_two_sample(const double* __restrict__ rs
     const int na = (int)(ai1 - ai0), nb = (int)(bi1 - bi0);
     int ai = (int)merge_path(LA, (i64)na, LB, (i64)nb, (i64)diag);
     int bi = diag - ai;
-    double ks = 0.0, w = 0.0;
-    const double inv_r = 1.0, inv_a = 1.0;
-    (void)inv_r; (void)inv_a;
+    double w = 0.0;
+    i64 ksn = 0;   // max |i*Ma - j*Mr|: the KS statistic is this integer over Mr*Ma (an exact rational)
     double ak = (ai < ca) ? sk[pos16(ai)] : 0.0, bk = (bi < cb) ? sk[pos16(ca + bi)] : 0.0;
     for (int i = 0; i < nout; ++i) {
         const bool takeA = (bi >= nb) || (ai < na && !(bk < ak));
@@ -63,12 +64,15 @@ __global__ __launch_bounds__(NT) void k_two_sample(const double* __restrict__ rs
         const bool last = !hasA && !hasB;
         const double nxt = (!hasB || (hasA && !(bk < ak))) ? ak : bk;
         if (last || nxt != v) {
-            const double diff = fabs((double)(ai0 + ai) / (double)Mr - (double)(bi0 + bi) / (double)Ma);
-            ks = fmax(ks, diff);
+            const i64 ci = ai0 + ai, cj = bi0 + bi;
+            const i64 num = ci * Ma - cj * Mr;
+            ksn = max(ksn, num < 0 ? -num : num);
+            const double diff = fabs((double)ci / (double)Mr - (double)cj / (double)Ma);
             if (!last) w = fma(diff, nxt - v, w);
         }
     }
     // block reduce
+    double ks = (double)ksn;   // exact: the numerator is below 2^53 (checked on the host)
     for (int o = 32; o > 0; o >>= 1) { ks = fmax(ks, __shfl_xor(ks, o, kWave)); w += __shfl_xor(w, o, kWave); }
     if ((tid & 63) == 0) { red[tid >> 6] = ks; red[NT / 64 + (tid >> 6)] = w; }
     __syncthreads();
@@ -80,14 +84,14 @@ __global__ __launch_bounds__(NT) void k_two_sample(const double* __restrict__ rs
     }
 }
 
-__global__ void k_two_sample_final(const double* __restrict__ part, int nblk, i64 P, double* __restrict__ ks,
-                                   double* __restrict__ w1)
+__global__ void k_two_sample_final(const double* __restrict__ part, int nblk, i64 P, double denom,
+                                   double* __restrict__ ks, double* __restrict__ w1)
 {
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     double m = 0.0, s = 0.0;
     for (int b = 0; b < nblk; ++b) { m = fmax(m, part[(p * nblk + b) * 2]); s += part[(p * nblk + b) * 2 + 1]; }
-    ks[p] = m;
+    ks[p] = m / denom;   // one correctly rounded division of the exact rational
     w1[p] = s;
 }
 
@@ -118,12 +122,12 @@ __global__ __launch_bounds__(64) void k_cov_mfma(const double* __restrict__ X, i
         const double b = (pj < P && tt < t1) ? xj[tt] - Kj : 0.0;    // B[k kq][col r]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
-    // D[4*(lane/16) + i][lane%16] = acc[i]
+    // result layout measured on gfx950 (tools/ubench/mfma64_layout.hip): D[(lane/16) + 4*i][lane%16] = acc[i]
     const i64 P16 = (i64)tiles * 16;
     double* out = partial + (i64)ks * P16 * P16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const i64 row = (i64)ti * 16 + 4 * kq + i, col = (i64)tj * 16 + r;
+        const i64 row = (i64)ti * 16 + kq + 4 * i, col = (i64)tj * 16 + r;
         out[row * P16 + col] = acc[i];
     }
 }
