@@ -67,6 +67,9 @@ def parse_args():
                     help="pcn = Arrow column layout [P][C][N]; cnp = Draws.to_numpy layout [C][N][P]")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--inflight", type=int, default=4, help="steps enqueued before a host wait (1..4)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the real N > 1 runs); gloo = CPU rendezvous for rehearsing the "
+                         "N > 1 control flow with several ranks sharing one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
     ap.add_argument("--no-moments", action="store_true",
@@ -90,7 +93,7 @@ def validate(got: dict, exp: dict) -> tuple[bool, float]:
     return bool(ok and worst <= 1e-6), worst
 
 
-def corpus_bench(a, ctx, world, rank, dist, torch):
+def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
     """BASELINE configs 2/3: one step = one pass over the whole 57-model corpus (shapes of the packaged
     reference set, synthetic draws), models LPT-sharded over ranks, same-shape models batched into one
     kernel pipeline, one RCCL all_gather of 128-byte records at the end."""
@@ -111,7 +114,11 @@ def corpus_bench(a, ctx, world, rank, dist, torch):
     def barrier():
         ctx.sync()
         if dist is not None:
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            if dist_dev == "cuda":
+                torch.cuda.synchronize()
+            dist.barrier()
+            if dist_dev == "cuda":
+                torch.cuda.synchronize()
 
     def run(steps):
         last = None
@@ -127,7 +134,7 @@ def corpus_bench(a, ctx, world, rank, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     recs = []
@@ -146,10 +153,10 @@ def corpus_bench(a, ctx, world, rank, dist, torch):
             valid = valid and ok
         t.free()
     local = np.concatenate(recs) if recs else np.empty((0, shard.RECORD_DOUBLES))
-    allrec = shard.gather_records(local, dist, device="cuda" if dist is not None else None)
+    allrec = shard.gather_records(local, dist, device=dist_dev)
     valid = valid and allrec.shape[0] == 460
     if dist is not None:
-        flag = torch.tensor([1.0 if valid else 0.0], device="cuda")
+        flag = torch.tensor([1.0 if valid else 0.0], device=dist_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         valid = bool(flag.item() > 0.5)
     if rank == 0:
@@ -177,16 +184,23 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dist = torch = None
+    dist_dev = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist_dev = "cuda"
+        else:   # rehearsal: ranks may share a GPU, collectives run on CPU tensors
+            dist.init_process_group("gloo")
+            dist_dev = "cpu"
 
     from mcmc_ref_hip import _ffi, synth
-    ctx = _ffi.Context(local_rank)
+    ndev = max(_ffi.load_library().mcr_device_count(), 1)
+    ctx = _ffi.Context(local_rank % ndev if a.dist_backend == "gloo" else local_rank)
     if a.workload == "corpus":
-        return corpus_bench(a, ctx, world, rank, dist, torch)
+        return corpus_bench(a, ctx, world, rank, dist, torch, dist_dev)
     C, N, P = a.chains, a.draws, a.params
     dt = np.float64 if a.dtype == "f64" else np.float32
     # independent models shard across ranks: rank r validates its own model (weak scaling)
@@ -198,9 +212,11 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if dist_dev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist_dev == "cuda":
+                torch.cuda.synchronize()
 
     def run(steps):
         last = None
@@ -230,7 +246,7 @@ def main():
     ctx.profile(False)
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     got = last.result()
@@ -240,7 +256,7 @@ def main():
     if dist is not None:
         from mcmc_ref_hip import shard
         mine = shard.pack_records(got, rank, C, N)
-        allrec = shard.gather_records(mine, dist, device="cuda")
+        allrec = shard.gather_records(mine, dist, device=dist_dev)
         sel = allrec[allrec[:, shard.RECORD_FIELDS.index("model_idx")] == rank]
         gathered_ok = allrec.shape[0] == world * P and np.array_equal(sel, mine, equal_nan=True)
 
@@ -258,7 +274,7 @@ def main():
                    "sample": f"the same {C}x{N}x{P} {a.dtype} model, 1 pass of oracle/mcr_oracle.c "
                              f"({cpu_s:.2f} s on {os.cpu_count()} available cores, 1 used)"}
     if dist is not None:
-        flag = torch.tensor([1.0 if (valid and gathered_ok) else 0.0], device="cuda")
+        flag = torch.tensor([1.0 if (valid and gathered_ok) else 0.0], device=dist_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         valid = bool(flag.item() > 0.5)
 
