@@ -65,7 +65,13 @@ struct mcr_ctx {
     hipStream_t stream = nullptr;
     char err[512] = "";
     size_t ws_limit = 0;
-    void* ws = nullptr; size_t ws_bytes = 0;
+    void* ws = nullptr; size_t ws_bytes = 0;          // workspace of the CURRENT lane (see use_lane)
+    // Lanes = streams with a workspace each (MCR_LANES, default 2): consecutive enqueues rotate lanes, so the
+    // tail of one call's kernels (partial last waves of workgroups) overlaps the next call's head.
+    hipStream_t lane_stream[MCR_MAX_INFLIGHT] = {};
+    void* lane_ws[MCR_MAX_INFLIGHT] = {};
+    size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
+    int lane = 0, n_lanes = 2;
     void* stage = nullptr; size_t stage_bytes = 0;  // device copy of host tensors (mcr_summarize)
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
@@ -143,8 +149,21 @@ void prof_resolve(mcr_ctx* ctx)
                         hipGetErrorString(le_));                                               \
     } while (0)
 
-void drop_graphs(mcr_ctx* ctx)   // stream must be idle
+void use_lane(mcr_ctx* ctx, int lane)
 {
+    ctx->lane_ws[ctx->lane] = ctx->ws; ctx->lane_ws_bytes[ctx->lane] = ctx->ws_bytes;   // save current
+    ctx->lane = lane;
+    ctx->stream = ctx->lane_stream[lane];
+    ctx->ws = ctx->lane_ws[lane]; ctx->ws_bytes = ctx->lane_ws_bytes[lane];
+}
+void sync_all(mcr_ctx* ctx)
+{
+    for (hipStream_t s : ctx->lane_stream) if (s) hipStreamSynchronize(s);
+}
+
+void drop_graphs(mcr_ctx* ctx)   // waits for every lane first (a cached graph may be in flight on any)
+{
+    sync_all(ctx);
     for (GraphEntry& g : ctx->graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
     ctx->graphs.clear();
@@ -462,6 +481,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     QArgs q;
     rc = prep_quantiles(ctx, quantiles, nq, M, q, s.qlo);
     if (rc) return rc;
+    use_lane(ctx, si % ctx->n_lanes);
     s.out = *out; s.P = P; s.M = M; s.nq = nq; s.C = (int)C;
     s.chunks.clear();
     s.trivial_nan = (M == 0 || P == 0);
@@ -575,7 +595,8 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
 
 int wait_impl(mcr_ctx* ctx)
 {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->lane_stream) if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
+    use_lane(ctx, 0);
     prof_resolve(ctx);
     int rc = MCR_OK;
     for (int si : ctx->order) {
@@ -592,7 +613,8 @@ int wait_impl(mcr_ctx* ctx)
 // Drops any enqueued-but-unwaited work after an error so the ctx stays usable.
 void abort_inflight(mcr_ctx* ctx)
 {
-    hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
+    use_lane(ctx, 0);
     prof_resolve(ctx);
     for (int si : ctx->order) ctx->slots[si].busy = false;
     ctx->order.clear();
@@ -602,7 +624,7 @@ void abort_inflight(mcr_ctx* ctx)
 int ensure_stage(mcr_ctx* ctx, size_t bytes)
 {
     if (bytes <= ctx->stage_bytes) return MCR_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    sync_all(ctx);
     if (ctx->stage) { hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
     HIP_TRY(ctx, hipMalloc(&ctx->stage, bytes));
     ctx->stage_bytes = bytes;
@@ -662,11 +684,19 @@ int mcr_init(int device, mcr_ctx** out)
     mcr_ctx* ctx = new (std::nothrow) mcr_ctx();
     if (!ctx) return fail(nullptr, MCR_ENOMEM, "out of host memory");
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    if (const char* env = getenv("MCR_LANES")) {
+        const int v = atoi(env);
+        ctx->n_lanes = v < 1 ? 1 : (v > MCR_MAX_INFLIGHT ? MCR_MAX_INFLIGHT : v);
+    }
+    e = hipSetDevice(device);
+    for (int l = 0; l < ctx->n_lanes && e == hipSuccess; ++l)
+        e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
         delete ctx;
         return fail(nullptr, MCR_EHIP, "device %d init failed: %s", device, hipGetErrorString(e));
     }
+    ctx->stream = ctx->lane_stream[0];
     size_t mb = 8192;
     if (const char* env = getenv("MCR_WORKSPACE_MB")) { const long v = atol(env); if (v > 0) mb = (size_t)v; }
     ctx->ws_limit = mb << 20;
@@ -679,7 +709,8 @@ void mcr_free(mcr_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);
+    use_lane(ctx, 0);
     prof_resolve(ctx);
     drop_graphs(ctx);
     for (hipEvent_t e : ctx->free_ev) hipEventDestroy(e);
@@ -689,9 +720,10 @@ void mcr_free(mcr_ctx* ctx)
         if (s.d_off) hipFree(s.d_off);
         if (s.h_off) hipHostFree(s.h_off);
     }
-    if (ctx->ws) hipFree(ctx->ws);
+    ctx->lane_ws[0] = ctx->ws;
+    for (void* w : ctx->lane_ws) if (w) hipFree(w);
     if (ctx->stage) hipFree(ctx->stage);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -737,7 +769,7 @@ int mcr_memcpy_d2h(mcr_ctx* ctx, void* hptr, const void* dptr, size_t bytes)
 int mcr_sync(mcr_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->lane_stream) if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
     return MCR_OK;
 }
 
@@ -782,6 +814,7 @@ int mcr_summarize(mcr_ctx* ctx, const void* draws, int dtype, int64_t C, int64_t
         rc = ensure_stage(ctx, (size_t)ext * es);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->stage, draws, (size_t)ext * es, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pipeline may run on the other lane
     }
     return mcr_summarize_dev(ctx, ctx->stage, dtype, C, N, P, sc, sn, sp, min_chains, quantiles, n_q, out);
 }
