@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--layout", choices=["pcn", "cnp"], default="pcn",
                     help="pcn = Arrow column layout [P][C][N]; cnp = Draws.to_numpy layout [C][N][P]")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--inflight", type=int, default=4, help="steps enqueued before a host wait (1..4)")
+    ap.add_argument("--inflight", type=int, default=8, help="steps enqueued before a host wait (1..8)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the real N > 1 runs); gloo = CPU rendezvous for rehearsing the "
                          "N > 1 control flow with several ranks sharing one GPU")

@@ -124,7 +124,7 @@ int mcr_summarize_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C,
 /* Asynchronous form: enqueues the whole pipeline on the ctx stream and returns; results
  * land in `out` (which must stay valid) when mcr_summarize_wait() returns.  At most
  * MCR_MAX_INFLIGHT enqueues may be outstanding per ctx. */
-#define MCR_MAX_INFLIGHT 4
+#define MCR_MAX_INFLIGHT 8
 int mcr_summarize_enqueue(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N,
                           int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
                           int min_chains, const double* quantiles, int n_q, mcr_summary* out);

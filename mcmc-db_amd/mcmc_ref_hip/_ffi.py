@@ -18,7 +18,7 @@ MCR_EINVAL, MCR_EMINCHAINS, MCR_EMINCHAINS_ARG, MCR_ENONFINITE = -1, -2, -3, -4
 MCR_EHIP, MCR_ENOMEM, MCR_ENODEVICE, MCR_ECOMM = -5, -6, -7, -8
 MCR_F64, MCR_F32 = 0, 1
 MCR_MAX_QUANTILES = 32
-MCR_MAX_INFLIGHT = 4
+MCR_MAX_INFLIGHT = 8
 
 _PKG = Path(__file__).resolve().parent
 DEFAULT_LIB = _PKG.parent / "lib" / "libmcmcref_hip.so"
