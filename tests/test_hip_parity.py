@@ -272,3 +272,50 @@ def test_sticky_chains_continuation_paths(ctx, oracle):
     exp = oracle.summarize(x, "pcn")
     assert int(exp["lag_bulk"].max()) > 255, exp["lag_bulk"]
     check_summary(got, exp, what="sticky")
+
+
+def test_random_shapes_fuzz(ctx, oracle):
+    """Seeded fuzz over shapes that cross every internal boundary: tile (4096) and bucket edges,
+    1..16 tiles, segment (2048) edges, odd N, tie-heavy and constant columns, both layouts, f32."""
+    rng = np.random.default_rng(2026)
+    n_choices = [2, 3, 5, 63, 64, 65, 127, 511, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6000, 9001]
+    for it in range(48):
+        C = int(rng.integers(2, 9))
+        N = int(rng.choice(n_choices))
+        if C * N > 65000 and it % 4:
+            N = 65000 // C
+        P = int(rng.integers(1, 5))
+        kind = it % 6
+        x = rng.normal(size=(P, C, N)) * 10.0 ** rng.integers(-3, 4) + rng.normal() * 100.0
+        if kind == 1:
+            x = np.round(x, 0)                                   # few distinct values
+        elif kind == 2:
+            x[0] = 3.25                                          # constant parameter
+        elif kind == 3:
+            x = np.cumsum(rng.normal(size=(P, C, N)), axis=2) * 0.05     # random walks: long lags
+        elif kind == 4 and C > 2:
+            x[:, 0, :] += 5.0                                    # one shifted chain
+        layout = "pcn"
+        arr = x
+        if it % 5 == 0:
+            arr = np.ascontiguousarray(np.transpose(x, (1, 2, 0))); layout = "cnp"
+        if it % 7 == 0:
+            arr = arr.astype(np.float32)
+        got = ctx.summarize(arr, layout, min_chains=2)
+        exp = oracle.summarize(arr, layout, min_chains=2)
+        check_summary(got, exp, what=f"fuzz{it} C={C} N={N} P={P} kind={kind} {layout} {arr.dtype}")
+
+
+def test_ragged_fuzz(ctx, oracle):
+    rng = np.random.default_rng(77)
+    for it in range(24):
+        C = int(rng.integers(2, 7))
+        lens = [int(rng.integers(1, 700)) for _ in range(C)]
+        if it % 3 == 0:
+            lens[int(rng.integers(0, C))] = int(rng.integers(2050, 5000))     # second-half range beyond min length
+        chains = [list(np.round(rng.normal(size=n), 2 if it % 2 else 8)) for n in lens]
+        got = ctx.diagnose_chains(chains, 2)
+        exp = oracle.diag(chains, 2)
+        for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
+            assert close(got[k], exp[k], TIGHT), (it, lens, k, got[k], exp[k])
+        assert (got["lag_bulk"], got["lag_tail"]) == (exp["lag_bulk"], exp["lag_tail"]), (it, lens)
