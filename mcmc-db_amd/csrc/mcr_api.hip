@@ -229,22 +229,30 @@ struct Carve {
 struct WsPlan {
     size_t per_param;  // bytes per parameter (upper bound incl. alignment slack handled separately)
     i64 ntiles;
-    int bk_B = 0, bk_D = 0;  // bucket path (ntiles <= kMaxBucketTiles): #buckets, samples per bucket
+    // bucket path: the pooled array is cut into bk_k <= 16 sorted runs of length bk_R (a tile, or tiles
+    // pre-merged by a few pairwise passes); #buckets, samples per bucket
+    int bk_B = 0, bk_D = 0, bk_k = 0;
+    i64 bk_R = 0;
 };
 
 WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
 {
     WsPlan w;
     w.ntiles = (M + kTile - 1) / kTile;
-    if (w.ntiles <= kMaxBucketTiles) {
-        const int k = (int)w.ntiles;
-        const i64 last = M - (w.ntiles - 1) * kTile;
-        const i64 sf = (w.ntiles - 1) * 64 + last / 64;   // finite regular samples
-        w.bk_D = (4096 - 79 * k) / 64;                     // 64*D + 64*k + 15*k <= 4096
-        w.bk_B = (int)((sf + w.bk_D - 1) / w.bk_D);
-        if (w.bk_B < 1) w.bk_B = 1;
+    {
+        i64 R = kTile;
+        while ((M + R - 1) / R > kMaxBucketTiles) R *= 2;
+        const i64 k = (M + R - 1) / R;
+        if (k * (R / 64) <= 8192) {                           // the samples of one parameter must fit LDS
+            const i64 last = M - (k - 1) * R;
+            const i64 sf = (k - 1) * (R / 64) + last / 64;    // finite regular samples
+            w.bk_R = R; w.bk_k = (int)k;
+            w.bk_D = (int)((4096 - 79 * k) / 64);             // 64*D + 64*k + 15*k <= 4096
+            w.bk_B = (int)((sf + w.bk_D - 1) / w.bk_D);
+            if (w.bk_B < 1) w.bk_B = 1;
+        }
     }
-    w.per_param = (size_t)w.ntiles * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.ntiles + 1) * 4 + 16 +
+    w.per_param = (size_t)(w.ntiles + 16) * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.bk_k + 1) * 4 + 16 +
                   (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
                   (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) *
@@ -274,7 +282,8 @@ struct PipeIn {
     double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
     u32* cut;            // [pc][B+1][ntiles]
     u32* boff;           // [pc][B+1]
-    int bk_B = 0, bk_D = 0;
+    int bk_B = 0, bk_D = 0, bk_k = 0;
+    i64 bk_R = 0;
     i64 ntiles;
     bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
 };
@@ -303,34 +312,43 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
 {
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
-    // 1. tile sort (+ moment partials, + regular samples for the bucket partition)
+    // 1. tile sort (+ moment partials, + regular samples when a tile is already a run)
     const bool bucket = a.bk_B > 0;
     LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<kSortNT, kSortVT>), dim3((unsigned)a.ntiles, py), dim3(kSortNT),
-           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles, bucket ? a.samp : (double*)nullptr);
+           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles,
+           (bucket && a.bk_R == kTile) ? a.samp : (double*)nullptr);
     double *kin = a.kA, *kout = a.kB;
     u32 *iin = a.iA, *iout = a.iB;
     const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
     bool ranked = false;
+    // 2. pairwise merge-path passes: up to the run length of the bucket partition, or all the way
+    const i64 Rstop = bucket ? a.bk_R : M;
+    for (i64 R = kTile; R < Rstop; R *= 2) {
+        LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
+               (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
+               (const i64*)nullptr, (double*)nullptr, (double*)nullptr);
+        std::swap(kin, kout);
+        std::swap(iin, iout);
+    }
     if (bucket) {
-        // 2a. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
-        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(1024), 0, (const double*)kin, (const double*)a.samp, M,
-               (int)a.ntiles, a.bk_B, a.bk_D, a.cut, a.boff);
+        // 3. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
+        if (a.bk_R != kTile)
+            LAUNCH(ctx, K_SPLITTERS, k_sample_runs, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const double*)kin, M,
+                   a.bk_R, a.samp);
+        const int S = a.bk_k * (int)(a.bk_R / 64);
+        const size_t lds_spl = (size_t)S * 12 + (size_t)(a.bk_B + 1) * 16 + (size_t)(a.bk_B + 1) * a.bk_k * 4 + 64;
+        if (lds_spl > 60 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
+        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
+               M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,
-               (const double*)kin, (const u32*)iin, kout, iout, M, (int)a.ntiles, a.bk_B, (const u32*)a.cut,
-               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc);
+               (const double*)kin, (const u32*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
+               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc, a.bk_R);
         std::swap(kin, kout);
         std::swap(iin, iout);
         ranked = true;
-    } else {
-        // 2b. long pooled arrays: pairwise merge-path passes
-        for (i64 R = kTile; R < M; R *= 2) {
-            LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
-                   (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-                   (const i64*)nullptr, (double*)nullptr, (double*)nullptr);
-            std::swap(kin, kout);
-            std::swap(iin, iout);
-        }
     }
     *kin_o = kin; *iin_o = iin; *kout_o = kout; *iout_o = iout; *ranked_o = ranked;
     return MCR_OK;
@@ -525,10 +543,10 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.state = cv.take<double>((size_t)pc * 2 * 4);
                 }
                 a.nstage = N > 0 ? N : 1;
-                a.samp = cv.take<double>((size_t)pc * wp.ntiles * 64);
-                a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)wp.ntiles);
+                a.samp = cv.take<double>((size_t)pc * (wp.ntiles + 16) * 64);
+                a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
-                a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
+                a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
                 a.rank_b = a.rank_t = nullptr;
                 a.do_diag = do_diag;
                 if (ingest) {
@@ -879,10 +897,10 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.state = cv.take<double>(8);
     }
     a.nstage = nstage;
-    a.samp = cv.take<double>((size_t)wp.ntiles * 64);
-    a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)wp.ntiles);
+    a.samp = cv.take<double>((size_t)(wp.ntiles + 16) * 64);
+    a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));
-    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
+    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
     double* X = cv.take<double>((size_t)M);
     a.rank_b = want_rank ? cv.take<double>((size_t)M) : nullptr;
     a.rank_t = want_rank ? cv.take<double>((size_t)M) : nullptr;
@@ -998,10 +1016,10 @@ static int carve_sort(mcr_ctx* ctx, Carve& cv, i64 M, i64 P, PipeIn& a)
     a.kA = cv.take<double>((size_t)P * M); a.kB = cv.take<double>((size_t)P * M);
     a.iA = cv.take<u32>((size_t)P * M);    a.iB = cv.take<u32>((size_t)P * M);
     a.part = cv.take<double>((size_t)P * wp.ntiles * 4);
-    a.samp = cv.take<double>((size_t)P * wp.ntiles * 64);
-    a.cut = cv.take<u32>((size_t)P * (wp.bk_B + 1) * (size_t)wp.ntiles);
+    a.samp = cv.take<double>((size_t)P * (wp.ntiles + 16) * 64);
+    a.cut = cv.take<u32>((size_t)P * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)P * (wp.bk_B + 1));
-    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D;
+    a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
     return MCR_OK;
 }
 

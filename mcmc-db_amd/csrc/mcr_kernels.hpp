@@ -581,7 +581,8 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact k-way partition by regular sampling (k = #tiles <= 16).
+// Exact k-way partition by regular sampling (k = #sorted runs <= 16; a run is a sorted tile, or the
+// result of a few pairwise merge passes when the pooled array is longer than 16 tiles).
 //
 // Every sorted tile contributes its 64th, 128th, ... order statistics.  In the strict total order
 // (value, tile, position) the sample of pooled sample-rank r has between 64(r+1) and 64(r+1)+64k
@@ -595,29 +596,32 @@ constexpr int kMaxBucketTiles = 16;
 
 __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ keys,
                                                     const double* __restrict__ samp, i64 M, int k, int B,
-                                                    int D, u32* __restrict__ cut, u32* __restrict__ boff)
+                                                    int D, i64 R, u32* __restrict__ cut, u32* __restrict__ boff)
 {
-    constexpr int T = 4096, SPT = 64, NTS = 1024;
-    __shared__ double sv[kMaxBucketTiles * SPT];
-    __shared__ int srank[kMaxBucketTiles * SPT];
-    __shared__ double splv[64];
-    __shared__ int splt[64], splp[64];
-    __shared__ u32 scut[65 * kMaxBucketTiles];
+    constexpr int NTS = 1024;
+    const int SPT = (int)(R / 64);                   // samples per run
+    const int S = k * SPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sv = reinterpret_cast<double*>(smem);    // S samples
+    double* splv = sv + S;                           // B splitter values
+    int* srank = reinterpret_cast<int*>(splv + B + 1);   // S pooled ranks
+    int* splt = srank + S;                           // B splitter run
+    int* splp = splt + B + 1;                        // B splitter position in run
+    u32* scut = reinterpret_cast<u32*>(splp + B + 1);    // (B+1) * k cuts
     const int tid = threadIdx.x;
     const i64 p = blockIdx.x;
     const double* kp = keys + p * M;
-    const int S = k * SPT;
     for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; srank[i] = i % SPT; }
     __syncthreads();
-    // pooled rank of every finite sample = own index + samples of every other tile below it;
-    // one (sample, other tile) pair per thread step
-    for (int q = tid; q < S * k; q += NTS) {
-        const int i = q / k, t2 = q % k;
+    // pooled rank of every finite sample = own index + samples of every other run below it;
+    // one (sample, other run) pair per thread step
+    for (i64 q = tid; q < (i64)S * k; q += NTS) {
+        const int i = (int)(q / k), t2 = (int)(q % k);
         const double v = sv[i];
         const int t = i / SPT;
         if (t2 == t || !(v < INFINITY)) continue;
         const double* a = sv + t2 * SPT;
-        int lo = 0, hi = SPT;  // count of samples of tile t2 that sort before (v, t, j)
+        int lo = 0, hi = SPT;  // count of samples of run t2 that sort before (v, t, j)
         if (t2 < t) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
         else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
         if (lo) atomicAdd(&srank[i], lo);
@@ -632,11 +636,11 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
         }
     }
     __syncthreads();
-    // cuts: position in tile t where bucket b starts
+    // cuts: position in run t where bucket b starts
     for (int q = tid; q < (B + 1) * k; q += NTS) {
         const int b = q / k, t = q % k;
-        const i64 tbase = (i64)t * T;
-        const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+        const i64 tbase = (i64)t * R;
+        const int cnt = (int)((M - tbase < R) ? M - tbase : R);
         u32 c;
         if (b == 0) c = 0;
         else if (b == B) c = (u32)cnt;
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
             const int ts = splt[b];
             if (t == ts) c = (u32)(splp[b] + 1);
             else {
-                // the tile's own samples (in LDS) bracket the answer to a 64-draw window
+                // the run's own samples (in LDS) bracket the answer to a 64-draw window
                 const double* sa = sv + t * SPT;
                 int slo = 0, shi = SPT;
                 if (t < ts) { while (slo < shi) { const int m = (slo + shi) >> 1; if (!(v < sa[m])) slo = m + 1; else shi = m; } }
@@ -670,6 +674,21 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
     }
 }
 
+// Every 64th order statistic of each sorted run of length R (the regular samples of k_splitters)
+// when the runs were produced by merge passes rather than by k_tile_sort.  grid (k, P).
+__global__ __launch_bounds__(256) void k_sample_runs(const double* __restrict__ keys, i64 M, i64 R,
+                                                     double* __restrict__ samp)
+{
+    const int run = blockIdx.x, k = gridDim.x;
+    const i64 p = blockIdx.y;
+    const int SPT = (int)(R / 64);
+    const i64 base = (i64)run * R;
+    for (int j = threadIdx.x; j < SPT; j += 256) {
+        const i64 e = base + 64 * (i64)j + 63;
+        samp[(p * k + run) * SPT + j] = (e < M && 64 * (i64)j + 63 < R) ? keys[p * M + e] : INFINITY;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Bucket merge: one workgroup per (bucket, parameter) gathers its <= k sorted pieces (one per tile)
 // into LDS, each padded with +inf to a multiple of 16, merges them with ceil(log2 k) merge-path
@@ -683,7 +702,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
                                                       double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                                       int k, int B, const u32* __restrict__ cut,
                                                       const u32* __restrict__ boff, double* __restrict__ z,
-                                                      double* __restrict__ rank_out, i64 P)
+                                                      double* __restrict__ rank_out, i64 P, i64 R)
 {
     constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -723,7 +742,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             if (t + step < k && e >= sst[t + step]) t += step;
         const int o = e - sst[t];
         double v = INFINITY; u32 id = 0xFFFFFFFFu;
-        if (o < spl[t]) { const i64 g = (i64)t * T + sps[t] + o; v = kp[g]; id = ip[g]; }
+        if (o < spl[t]) { const i64 g = (i64)t * R + sps[t] + o; v = kp[g]; id = ip[g]; }
         skey[pos16(e)] = v; sidx[pos16(e)] = id;
     }
     __syncthreads();
@@ -765,8 +784,8 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     if (tid < 64) {
         bool e0 = false, e1 = false;
         if (tid < k) {
-            const i64 tbase = (i64)tid * T;
-            const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+            const i64 tbase = (i64)tid * R;
+            const int cnt = (int)((M - tbase < R) ? M - tbase : R);
             const int lo = sps[tid], hi = sps[tid] + spl[tid];
             if (lo > 0) e0 = (kp[tbase + lo - 1] == skey[pos16(0)]);
             if (hi < cnt) e1 = (kp[tbase + hi] == skey[pos16(total - 1)]);
@@ -779,8 +798,8 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     if ((ext0 || ext1) && tid < 2 * k) {
         const int t = tid % k, which = tid / k;           // 0: first value, 1: last value
         const double v = which ? skey[pos16(total - 1)] : skey[pos16(0)];
-        const i64 tbase = (i64)t * T;
-        const int cnt = (int)((M - tbase < (i64)T) ? M - tbase : (i64)T);
+        const i64 tbase = (i64)t * R;
+        const int cnt = (int)((M - tbase < R) ? M - tbase : R);
         const double* a = kp + tbase;
         int lo = 0, hi = cnt;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
