@@ -229,23 +229,31 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 
 // Serial merge of up to VT outputs from LDS runs A = skey[pos(a0 + .)] (na items) and
 // B = skey[pos(b0 + .)] (nb items), starting at (ai, bi).  src[i] = LDS slot the output came from.
+// Branch-free: an exhausted run shows a +inf head, the LDS read of the next head is unconditional
+// (one slot past a run is still inside the workgroup's LDS) and masked afterwards.  Keys of real
+// draws are finite, so they are never confused with the sentinel; among +inf pads the payload may
+// come from either side, which is irrelevant (pads are never written out).  ~20 VALU per output.
 template <int VT>
 __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na, int b0, int nb, int ai,
                                              int bi, int nout, double (&k)[VT], int (&src)[VT])
 {
-    double ak = (ai < na) ? skey[pos16(a0 + ai)] : 0.0;
-    double bk = (bi < nb) ? skey[pos16(b0 + bi)] : 0.0;
+    int pa = a0 + ai, pb = b0 + bi;
+    const int ea = a0 + na, eb = b0 + nb;
+    double ak = skey[pos16(pa)], bk = skey[pos16(pb)];
+    ak = (pa < ea) ? ak : INFINITY;
+    bk = (pb < eb) ? bk : INFINITY;
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         if (i < nout) {
-            const bool takeA = (bi >= nb) || (ai < na && !(bk < ak));
+            const bool takeA = !(bk < ak);
             k[i] = takeA ? ak : bk;
-            src[i] = takeA ? a0 + ai : b0 + bi;
-            ai += takeA ? 1 : 0;
-            bi += takeA ? 0 : 1;
-            const int nxt = takeA ? a0 + ai : b0 + bi;
-            const bool ok = takeA ? (ai < na) : (bi < nb);
-            const double nv = ok ? skey[pos16(nxt)] : 0.0;
+            src[i] = takeA ? pa : pb;
+            pa += takeA ? 1 : 0;
+            pb += takeA ? 0 : 1;
+            const int pn = takeA ? pa : pb;
+            const int en = takeA ? ea : eb;
+            double nv = skey[pos16(pn)];
+            nv = (pn < en) ? nv : INFINITY;
             ak = takeA ? nv : ak;
             bk = takeA ? bk : nv;
         } else {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event timings for a few synthetic shapes (development aid)."""
-import sys, time
+import os, sys, time
+os.environ.setdefault("MCR_LANES", "1")   # per-kernel timings of kernels running alone
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
