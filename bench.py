@@ -219,11 +219,12 @@ def main():
                 torch.cuda.synchronize()
 
     def run(steps):
+        """Rolling window: at most `inflight` steps outstanding, the device never drains in between."""
         last = None
         for k in range(steps):
+            if ctx.inflight >= inflight:
+                ctx.wait_one()
             last = ctx.enqueue(t)
-            if (k + 1) % inflight == 0:
-                ctx.wait()
         ctx.wait()
         return last
 

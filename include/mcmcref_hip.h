@@ -129,6 +129,9 @@ int mcr_summarize_enqueue(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_
                           int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
                           int min_chains, const double* quantiles, int n_q, mcr_summary* out);
 int mcr_summarize_wait(mcr_ctx* ctx);
+/* Waits for the OLDEST outstanding enqueue only and fills its `out`; later enqueues keep running, so a
+ * caller can hold a rolling window of MCR_MAX_INFLIGHT calls without ever draining the device. */
+int mcr_summarize_wait_one(mcr_ctx* ctx);
 
 /* diagnostics.split_rhat / ess_bulk / ess_tail for ONE parameter given as possibly ragged
  * chains (src/mcmc_ref/diagnostics.py:13-73): `pooled` holds the chains back to back, chain c

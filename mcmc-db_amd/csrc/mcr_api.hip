@@ -46,6 +46,8 @@ struct Slot {
     mcr_summary out{};
     i64 P = 0, M = 0; int nq = 0; int C = 0;
     bool trivial_nan = false;  // M == 0: no kernels ran
+    hipEvent_t done = nullptr;  // recorded on the slot's lane after its last copy (mcr_summarize_wait_one)
+    int lane = 0;
     i64 qlo[MCR_MAX_QUANTILES];
     std::vector<Chunk> chunks;
 };
@@ -604,11 +606,28 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             if (rc) return rc;
         }
     }
+    if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+    s.lane = ctx->lane;
     s.busy = true;
     ctx->order.push_back(si);
     ctx->n_inflight++;
     ctx->next_slot = (si + 1) % MCR_MAX_INFLIGHT;
     return MCR_OK;
+}
+
+// Waits for the OLDEST outstanding enqueue only and delivers its results; the others keep running.
+int wait_one_impl(mcr_ctx* ctx)
+{
+    if (ctx->order.empty()) return MCR_OK;
+    const int si = ctx->order.front();
+    Slot& s = ctx->slots[si];
+    HIP_TRY(ctx, hipEventSynchronize(s.done));
+    const int rc = unpack_slot(ctx, s);
+    s.busy = false;
+    ctx->order.erase(ctx->order.begin());
+    ctx->n_inflight--;
+    return rc;
 }
 
 int wait_impl(mcr_ctx* ctx)
@@ -733,6 +752,7 @@ void mcr_free(mcr_ctx* ctx)
     drop_graphs(ctx);
     for (hipEvent_t e : ctx->free_ev) hipEventDestroy(e);
     for (Slot& s : ctx->slots) {
+        if (s.done) hipEventDestroy(s.done);
         if (s.d_res) hipFree(s.d_res);
         if (s.h_res) hipHostFree(s.h_res);
         if (s.d_off) hipFree(s.d_off);
@@ -809,6 +829,12 @@ int mcr_summarize_wait(mcr_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
     return wait_impl(ctx);
+}
+
+int mcr_summarize_wait_one(mcr_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    return wait_one_impl(ctx);
 }
 
 int mcr_summarize_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t sc,

@@ -68,6 +68,7 @@ SYMBOLS = {
     "mcr_summarize_dev": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
     "mcr_summarize_enqueue": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
     "mcr_summarize_wait": (C.c_int, [C.c_void_p]),
+    "mcr_summarize_wait_one": (C.c_int, [C.c_void_p]),
     "mcr_diagnose_chains": (C.c_int, [C.c_void_p, _dp, _ip, C.c_int, C.c_int, C.POINTER(Summary),
                                       _dp, _dp, _dp, _dp]),
     "mcr_basic_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _dp, _dp]),
@@ -305,6 +306,18 @@ class Context:
             self._check(self.lib.mcr_summarize_wait(self.handle))
         finally:
             self._pending.clear()
+
+    def wait_one(self) -> SummaryBuffers | None:
+        """Wait for the oldest outstanding enqueue only; returns its buffers (None if nothing is pending)."""
+        if not self._pending:
+            return None
+        bufs = self._pending.pop(0)
+        self._check(self.lib.mcr_summarize_wait_one(self.handle))
+        return bufs
+
+    @property
+    def inflight(self) -> int:
+        return len(self._pending)
 
     def diagnose_chains(self, chains, min_chains: int = 4, debug: bool = False) -> dict:
         """split_rhat / ess_bulk / ess_tail of ONE parameter given as (possibly ragged) chains."""

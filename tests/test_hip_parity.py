@@ -319,3 +319,26 @@ def test_ragged_fuzz(ctx, oracle):
         for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
             assert close(got[k], exp[k], TIGHT), (it, lens, k, got[k], exp[k])
         assert (got["lag_bulk"], got["lag_tail"]) == (exp["lag_bulk"], exp["lag_tail"]), (it, lens)
+
+
+def test_rolling_window_wait_one(ctx, oracle):
+    """mcr_summarize_wait_one: a rolling window of outstanding calls over two lanes delivers every
+    result, in order, without draining the device."""
+    from mcmc_ref_hip import _ffi, synth
+    xs = [synth.c1_model(4, 1500 + 100 * i, 3, seed=40 + i) for i in range(3)]
+    ts = [ctx.upload(x, "pcn") for x in xs]
+    exps = [oracle.summarize(x, "pcn") for x in xs]
+    done = []
+    try:
+        for k in range(20):
+            if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
+                done.append(ctx.wait_one())
+            ctx.enqueue(ts[k % 3])
+        while ctx.inflight:
+            done.append(ctx.wait_one())
+        assert len(done) == 20 and ctx.wait_one() is None
+        for k, b in enumerate(done):
+            check_summary(b.result(), exps[k % 3], what=f"rolling{k}")
+    finally:
+        for t in ts:
+            t.free()
