@@ -68,12 +68,12 @@ struct mcr_ctx {
     char err[512] = "";
     size_t ws_limit = 0;
     void* ws = nullptr; size_t ws_bytes = 0;          // workspace of the CURRENT lane (see use_lane)
-    // Lanes = streams with a workspace each (MCR_LANES, default 2): consecutive enqueues rotate lanes, so the
+    // Lanes = streams with a workspace each (MCR_LANES, default 4): consecutive enqueues rotate lanes, so the
     // tail of one call's kernels (partial last waves of workgroups) overlaps the next call's head.
     hipStream_t lane_stream[MCR_MAX_INFLIGHT] = {};
     void* lane_ws[MCR_MAX_INFLIGHT] = {};
     size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
-    int lane = 0, n_lanes = 2;
+    int lane = 0, n_lanes = 4;
     void* stage = nullptr; size_t stage_bytes = 0;  // device copy of host tensors (mcr_summarize)
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
