@@ -136,41 +136,53 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
     const int seglen = (int)((n - s0 < 0) ? 0 : ((n - s0 < (i64)kSeg) ? n - s0 : (i64)kSeg));
 
     if (FIRST) {
-        // ---- stage (9 loads in flight per lane) + segment sums ----
-        double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0, dummy = 0.0;
+        // ---- stage (9 loads in flight per lane) + segment sums; all index tests in 32-bit,
+        //      relative to the segment start ----
+        auto rel = [&](i64 x) -> int { const i64 d = x - s0; return (int)(d < 0 ? 0 : (d > kSeg + 80 ? kSeg + 80 : d)); };
+        const int r_load = rel(nload);                      // draws [0, r_load) of the window exist
+        const int r_n = rel(n);                             // draws [0, r_n) enter the products
+        const int own = (r_load < kSeg) ? r_load : kSeg;    // this workgroup owns window slots [0, own)
+        const int a0 = (hc > 0) ? rel(0) : 0, a1 = (hc > 0) ? rel(nh) : 0;             // first half
+        const int b0 = (hc > 0) ? rel(hc) : 0, b1 = (hc > 0) ? rel(hc + nh) : 0;        // second half
+        double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0;
         double vmin = INFINITY, vmax = -INFINITY;
         double v[9];
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
-            const i64 g = s0 + u * NT + tid;
-            v[u] = (u * NT + tid < kSeg + 80 && g < nload) ? zc[g] : 0.0;
+            const int j = u * NT + tid;
+            v[u] = (j < r_load) ? zc[s0 + j] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int j = u * NT + tid;
-            const i64 g = s0 + j;
             if (j < kSeg + 80) {
-                if (j < kSeg && g < nload) {       // this workgroup owns draw g
-                    if (g < n) { S += v[u]; vmin = fmin(vmin, v[u]); vmax = fmax(vmax, v[u]); }
-                    if (hc > 0) {
-                        if (g < nh) { S0 += v[u]; Q0 = fma(v[u], v[u], Q0); }
-                        if (g >= hc && g < hc + nh) { S1 += v[u]; Q1 = fma(v[u], v[u], Q1); }
-                    }
+                const double x = v[u];
+                if (j < own) {
+                    if (j < r_n) { S += x; vmin = fmin(vmin, x); vmax = fmax(vmax, x); }
+                    if (j >= a0 && j < a1) { S0 += x; Q0 = fma(x, x, Q0); }
+                    if (j >= b0 && j < b1) { S1 += x; Q1 = fma(x, x, Q1); }
                 }
-                sB[pos8(j)] = (g < n) ? v[u] : 0.0;
+                sB[pos8(j)] = (j < r_n) ? x : 0.0;
             }
         }
-        block_sum3<NT>(S, S0, Q0, red);
-        block_sum3<NT>(S1, Q1, dummy, red);
+        // one barrier pair for the five sums and min / max
+        S = wave_sum(S); S0 = wave_sum(S0); Q0 = wave_sum(Q0); S1 = wave_sum(S1); Q1 = wave_sum(Q1);
         for (int o = 32; o > 0; o >>= 1) {
             vmin = fmin(vmin, __shfl_xor(vmin, o, kWave));
             vmax = fmax(vmax, __shfl_xor(vmax, o, kWave));
         }
-        if ((tid & 63) == 0) { wred[tid >> 6] = vmin; wred[NW + (tid >> 6)] = vmax; }
+        if ((tid & 63) == 0) {
+            double* q = wred + (tid >> 6) * 8;
+            q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = vmin; q[6] = vmax;
+        }
         __syncthreads();
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;
         if (tid == 0) {
-            for (int w = 1; w < NW; ++w) { vmin = fmin(vmin, wred[w]); vmax = fmax(vmax, wred[NW + w]); }
+            for (int w = 1; w < NW; ++w) {
+                const double* q = wred + w * 8;
+                S += q[0]; S0 += q[1]; Q0 += q[2]; S1 += q[3]; Q1 += q[4];
+                vmin = fmin(vmin, q[5]); vmax = fmax(vmax, q[6]);
+            }
             r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
             r[SG_MIN] = vmin; r[SG_MAX] = vmax;
         }
