@@ -3,14 +3,19 @@
 // Per model (C chains x N draws, M = C*N pooled draws per parameter, P parameters) the pipeline is
 //
 //   k_ingest_*      (only if the tensor is not already f64 [P][C][N])  strided/f32 -> X[P][M] f64
-//   k_tile_sort     X -> sorted tiles of (key f64, idx u32) + per-tile shifted moment partials
-//   k_merge<false>  log2(#tiles) merge-path passes -> pooled ascending order per parameter
-//   k_order_stats   quantiles, median, fold split point                         (a2/a3/a8)
-//   k_rank_z        tie-averaged ranks -> z = Phi^-1((r-0.5)/M), scattered to time order (a7)
-//   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort) (a8)
-//   k_rank_z        same for the folded values
-//   k_acov_seg / k_diag_combine (mcr_diag.hpp)  split R-hat + ESS for bulk and folded z (a9-a13)
+//   k_tile_sort     X -> sorted 4096-draw tiles of (key f64, idx u32) + shifted moment partials
+//                   + every 64th order statistic of each tile
+//   k_merge<false>  only for M > 64K: pairwise merge-path passes until at most 16 sorted runs remain
+//                   (k_sample_runs then takes the regular samples of those runs)
+//   k_splitters     exact k-way partition by regular sampling: deterministic bucket bound
+//   k_bucket_merge  per bucket: gather <= 16 sorted pieces, merge in LDS, write the pooled ascending
+//                   order, and (fused) tie-averaged ranks -> z = Phi^-1((r-0.5)/M) -> time order   (a7)
+//   k_order_stats   quantiles, median, fold split point                                        (a2/a3/a8)
+//   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort), fused
+//                   with ranks -> z of the folded values                                          (a8, a7)
+//   k_acov_seg / k_diag_combine (mcr_diag.hpp)  split R-hat + ESS for bulk and folded z          (a9-a13)
 //   k_finalize      mean/std from partials, rhat = pymax(bulk, tail), packs the result table
+//   (k_rank_z: the standalone rank kernel, used only when M > 512K and no bucket partition applies)
 //
 // (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
 #pragma once
@@ -352,27 +357,6 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
     if (tid == 0) {
         double* o = part + (p * ntiles + tile) * 4;
         o[0] = s1; o[1] = s2; o[2] = bad; o[3] = 0.0;
-    }
-}
-
-// Tie run of sorted LDS position i inside [0, total): returns [s, e) (gallop + bisect in LDS).
-__device__ __forceinline__ void lds_tie_run(const double* skey, int total, int i, int& s, int& e)
-{
-    const double v = skey[pos16(i)];
-    s = i; e = i + 1;
-    if (i > 0 && skey[pos16(i - 1)] == v) {
-        int step = 1, hi = i - 1, lo = hi - step;
-        while (lo >= 0 && skey[pos16(lo)] == v) { hi = lo; step <<= 1; lo = hi - step; }
-        if (lo < -1) lo = -1;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) hi = m; else lo = m; }
-        s = hi;
-    }
-    if (i + 1 < total && skey[pos16(i + 1)] == v) {
-        int step = 1, lo = i + 1, hi = lo + step;
-        while (hi < total && skey[pos16(hi)] == v) { lo = hi; step <<= 1; hi = lo + step; }
-        if (hi > total) hi = total;
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (skey[pos16(m)] == v) lo = m; else hi = m; }
-        e = lo + 1;
     }
 }
 
