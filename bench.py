@@ -121,10 +121,17 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
                 torch.cuda.synchronize()
 
     def run(steps):
+        """Rolling window over (step, tensor group): the device never drains between corpus passes."""
+        from mcmc_ref_hip import _ffi
         last = None
         for _ in range(steps):
-            last = [ctx.enqueue(t) for _, _, t in tensors]
-            ctx.wait()
+            cur = []
+            for _, _, t in tensors:
+                if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
+                    ctx.wait_one()
+                cur.append(ctx.enqueue(t))
+            last = cur
+        ctx.wait()
         return last
 
     run(a.warmup)

@@ -133,6 +133,21 @@ int mcr_summarize_wait(mcr_ctx* ctx);
  * caller can hold a rolling window of MCR_MAX_INFLIGHT calls without ever draining the device. */
 int mcr_summarize_wait_one(mcr_ctx* ctx);
 
+/* Many independent models in one call (BASELINE configs 2/3: the packaged corpus): every model is a
+ * device-resident tensor of this ctx; the calls are pipelined through the lanes with a rolling window
+ * of MCR_MAX_INFLIGHT, so small models overlap.  Replaces the per-model loop of
+ * generate.generate_reference_corpus -> convert_file (src/mcmc_ref/generate.py:77-96).  outs[i] receives
+ * model i.  Stops at the first failing model and returns its code (earlier models are delivered). */
+typedef struct mcr_model_desc {
+    const void* draws_dev;
+    int dtype;
+    int min_chains;
+    int64_t C, N, P;
+    int64_t stride_c, stride_n, stride_p;
+} mcr_model_desc;
+int mcr_summarize_models(mcr_ctx* ctx, const mcr_model_desc* models, int n_models, const double* quantiles,
+                         int n_q, mcr_summary* outs);
+
 /* diagnostics.split_rhat / ess_bulk / ess_tail for ONE parameter given as possibly ragged
  * chains (src/mcmc_ref/diagnostics.py:13-73): `pooled` holds the chains back to back, chain c
  * is pooled[chain_off[c] .. chain_off[c+1]).  Host pointers.  out arrays have 1 entry.

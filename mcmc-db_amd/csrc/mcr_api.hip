@@ -837,6 +837,26 @@ int mcr_summarize_wait_one(mcr_ctx* ctx)
     return wait_one_impl(ctx);
 }
 
+int mcr_summarize_models(mcr_ctx* ctx, const mcr_model_desc* models, int n_models, const double* quantiles,
+                         int n_q, mcr_summary* outs)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (n_models < 0 || (n_models > 0 && (!models || !outs))) return fail(ctx, MCR_EINVAL, "bad argument");
+    int rc = MCR_OK;
+    for (int i = 0; i < n_models && !rc; ++i) {
+        if (ctx->n_inflight >= MCR_MAX_INFLIGHT) rc = wait_one_impl(ctx);
+        if (rc) break;
+        const mcr_model_desc& m = models[i];
+        rc = mcr_summarize_enqueue(ctx, m.draws_dev, m.dtype, m.C, m.N, m.P, m.stride_c, m.stride_n, m.stride_p,
+                                   m.min_chains, quantiles, n_q, &outs[i]);
+    }
+    char keep[512];
+    memcpy(keep, ctx->err, sizeof keep);
+    const int rw = wait_impl(ctx);          // deliver everything that was enqueued
+    if (rc) { memcpy(ctx->err, keep, sizeof keep); return rc; }
+    return rw;
+}
+
 int mcr_summarize_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t sc,
                       int64_t sn, int64_t sp, int min_chains, const double* quantiles, int n_q, mcr_summary* out)
 {

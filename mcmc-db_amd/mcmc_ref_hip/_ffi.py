@@ -45,6 +45,12 @@ class Summary(C.Structure):
                [("lag_bulk", _ip), ("lag_tail", _ip), ("q_lo", _ip)]
 
 
+class ModelDesc(C.Structure):
+    _fields_ = [("draws_dev", C.c_void_p), ("dtype", C.c_int), ("min_chains", C.c_int),
+                ("C", C.c_int64), ("N", C.c_int64), ("P", C.c_int64),
+                ("stride_c", C.c_int64), ("stride_n", C.c_int64), ("stride_p", C.c_int64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -67,6 +73,7 @@ SYMBOLS = {
     "mcr_summarize": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
     "mcr_summarize_dev": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
     "mcr_summarize_enqueue": (C.c_int, [C.c_void_p] + _TENSOR + [C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
+    "mcr_summarize_models": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, _dp, C.c_int, C.POINTER(Summary)]),
     "mcr_summarize_wait": (C.c_int, [C.c_void_p]),
     "mcr_summarize_wait_one": (C.c_int, [C.c_void_p]),
     "mcr_diagnose_chains": (C.c_int, [C.c_void_p, _dp, _ip, C.c_int, C.c_int, C.POINTER(Summary),
@@ -300,6 +307,22 @@ class Context:
                                                    qs.size, C.byref(bufs.struct)))
         self._pending.append(bufs)
         return bufs
+
+    def summarize_models(self, tensors, min_chains: int = 4, quantiles=(0.05, 0.5, 0.95)) -> list[dict]:
+        """One C call for a list of DeviceTensors (independent models), pipelined through the lanes."""
+        qs = self._quantiles(quantiles)
+        n = len(tensors)
+        descs = (ModelDesc * max(n, 1))()
+        outs = (Summary * max(n, 1))()
+        bufs = []
+        for i, t in enumerate(tensors):
+            code, C_, N, P, sc, sn, sp = t.targs
+            descs[i] = ModelDesc(t.buf.ptr, code, int(min_chains), C_, N, P, sc, sn, sp)
+            b = SummaryBuffers(P, qs.size)
+            outs[i] = b.struct
+            bufs.append(b)
+        self._check(self.lib.mcr_summarize_models(self.handle, descs, n, _as_dp(qs), qs.size, outs))
+        return [b.result() for b in bufs]
 
     def wait(self):
         try:

@@ -249,3 +249,29 @@ def test_corpus_shaped_batch_matches_per_model(oracle):
         rows = batched[batched[:, F.index("model_idx")] == mi]
         assert np.array_equal(rows[:, F.index("lag_bulk")], exp["lag_bulk"])
         assert np.allclose(rows[:, F.index("ess_tail")], exp["ess_tail"], rtol=1e-9)
+
+
+def test_summarize_models_c_abi(oracle):
+    """mcr_summarize_models: many independent models in one C call (rolling window over the lanes)."""
+    from mcmc_ref_hip import _ffi, synth
+    ctx = _ffi.default_context()
+    shapes = [(4, 700, 3), (10, 1000, 2), (4, 2500, 1), (6, 64, 4), (4, 4097, 2)] * 3      # 15 models > window
+    xs = [synth.c1_model(C, N, P, seed=100 + i) for i, (C, N, P) in enumerate(shapes)]
+    ts = [ctx.upload(x, "pcn") for x in xs]
+    try:
+        res = ctx.summarize_models(ts)
+        assert len(res) == len(xs)
+        for x, r in zip(xs, res):
+            exp = oracle.summarize(x, "pcn")
+            assert np.array_equal(r["lag_bulk"], exp["lag_bulk"]) and np.array_equal(r["q"], exp["q"])
+            assert np.allclose(r["ess_tail"], exp["ess_tail"], rtol=1e-9) and np.allclose(r["rhat"], exp["rhat"], rtol=1e-9)
+        # a failing model in the middle: its code comes back, the context stays usable
+        bad = ctx.upload(np.zeros((1, 2, 10)), "pcn")
+        with pytest.raises(_ffi.McrError) as ei:
+            ctx.summarize_models([ts[0], bad, ts[1]])
+        assert ei.value.code == _ffi.MCR_EMINCHAINS
+        bad.free()
+        assert len(ctx.summarize_models(ts[:2])) == 2
+    finally:
+        for t in ts:
+            t.free()
