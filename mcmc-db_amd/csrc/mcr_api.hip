@@ -293,15 +293,29 @@ struct PipeIn {
 // Split R-hat + ESS: segment products, combine, flagged continuation (mcr_diag.hpp).
 int launch_diag(mcr_ctx* ctx, const PipeIn& a)
 {
-    const int nseg = (int)((a.nstage + kSeg - 1) / kSeg);
+    // short chains (<= 1024 draws, e.g. the packaged corpus): half-size segments on 128-thread
+    // workgroups, so twice as many of the latency-bound workgroups are resident per CU
+    const bool small = a.nstage <= 1024;
+    const int seg = small ? 1024 : kSeg;
+    const int nseg = (int)((a.nstage + seg - 1) / seg);
     const unsigned pk = (unsigned)(2 * a.pc);
-    LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<256, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0, a.zb,
-           a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+    if (small) {
+        LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<128, 1024, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
+               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+    } else {
+        LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<256, kSeg, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
+               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+    }
     LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, a.zb, a.zt, a.M,
            a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate);
     // continuation for pairs whose first negative rho lies beyond lag 63 (others exit at once)
-    LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<256, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0, a.zb,
-           a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+    if (small) {
+        LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
+               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+    } else {
+        LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<256, kSeg, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
+               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+    }
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(256), (size_t)2 * a.C * 8, a.zb, a.zt, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, (const double*)a.state,
            (const double*)a.chstate, a.d_res, a.pc);

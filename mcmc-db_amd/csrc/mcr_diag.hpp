@@ -28,7 +28,7 @@
 
 namespace mcr {
 
-constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup
+constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (1024 for chains of <= 1024 draws)
 constexpr int kSegRec = 80;     // doubles per first-pass record: 64 lag products + 7 scalars
 constexpr int kMoreBlocks = 3;  // continuation pass covers lags 64 .. 64 + 64*3 - 1 = 255
 enum SegField { SG_S = 64, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
@@ -109,14 +109,14 @@ __device__ __forceinline__ void seg_products(const double* __restrict__ A, const
 // FIRST == true : lags 0..63 + the segment's sums (record of kSegRec doubles), every pair.
 // FIRST == false: lags 64..64+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
 // grid (nseg, C, 2 * P); blockIdx.z = 2 * p + kind.
-template <int NT, bool FIRST>
+template <int NT, int SEG, bool FIRST>
 __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, const double* __restrict__ zt,
                                                  i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
                                                  int nseg, const unsigned* __restrict__ more,
                                                  double* __restrict__ rec)
 {
     constexpr int NW = NT / kWave;
-    constexpr int LA = (kSeg + 16) / 8 * 10, LB = (kSeg + 80) / 8 * 10;
+    constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + 80) / 8 * 10;
     __shared__ __attribute__((aligned(16))) double sB[LB];
     __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
     __shared__ double tot[64];
@@ -132,16 +132,16 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
     const i64 nc = off[c + 1] - off[c], hc = nc / 2;
     const i64 hspan = (hc > 0) ? hc + nh : 0;
     const i64 nload = (n > hspan) ? n : hspan;          // <= nc
-    const i64 s0 = (i64)seg * kSeg;
-    const int seglen = (int)((n - s0 < 0) ? 0 : ((n - s0 < (i64)kSeg) ? n - s0 : (i64)kSeg));
+    const i64 s0 = (i64)seg * SEG;
+    const int seglen = (int)((n - s0 < 0) ? 0 : ((n - s0 < (i64)SEG) ? n - s0 : (i64)SEG));
 
     if (FIRST) {
         // ---- stage (9 loads in flight per lane) + segment sums; all index tests in 32-bit,
         //      relative to the segment start ----
-        auto rel = [&](i64 x) -> int { const i64 d = x - s0; return (int)(d < 0 ? 0 : (d > kSeg + 80 ? kSeg + 80 : d)); };
+        auto rel = [&](i64 x) -> int { const i64 d = x - s0; return (int)(d < 0 ? 0 : (d > SEG + 80 ? SEG + 80 : d)); };
         const int r_load = rel(nload);                      // draws [0, r_load) of the window exist
         const int r_n = rel(n);                             // draws [0, r_n) enter the products
-        const int own = (r_load < kSeg) ? r_load : kSeg;    // this workgroup owns window slots [0, own)
+        const int own = (r_load < SEG) ? r_load : SEG;    // this workgroup owns window slots [0, own)
         const int a0 = (hc > 0) ? rel(0) : 0, a1 = (hc > 0) ? rel(nh) : 0;             // first half
         const int b0 = (hc > 0) ? rel(hc) : 0, b1 = (hc > 0) ? rel(hc + nh) : 0;        // second half
         double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int j = u * NT + tid;
-            if (j < kSeg + 80) {
+            if (j < SEG + 80) {
                 const double x = v[u];
                 if (j < own) {
                     if (j < r_n) { S += x; vmin = fmin(vmin, x); vmax = fmax(vmax, x); }
@@ -194,12 +194,12 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
             for (int j = tid; j < 64 * kMoreBlocks; j += NT) r[j] = 0.0;
             return;
         }
-        for (int j = tid; j < kSeg + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+        for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zc[g] : 0.0; }
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
         for (int blk = 0; blk < kMoreBlocks; ++blk) {
             const i64 lb = 64 + 64 * blk;
             __syncthreads();
-            for (int j = tid; j < kSeg + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+            for (int j = tid; j < SEG + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zc[g] : 0.0; }
             __syncthreads();
             seg_products<NT>(sA, sB, seglen, tot, wred);
             if (tid < 64) r[blk * 64 + tid] = tot[tid];
