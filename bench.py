@@ -55,8 +55,8 @@ def alg_bytes(name: str, es: int) -> float:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["c1", "corpus"], default="c1",
                     help="c1 = BASELINE config 1 (default, the headline); corpus = configs 2/3: the 57 packaged "
                          "model shapes (4.6 M param-draws), LPT-sharded over ranks (strong scaling)")

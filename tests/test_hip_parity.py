@@ -342,3 +342,26 @@ def test_rolling_window_wait_one(ctx, oracle):
     finally:
         for t in ts:
             t.free()
+
+
+def test_inflight_limit_and_context_reuse(ctx, oracle):
+    """More than MCR_MAX_INFLIGHT outstanding calls is an argument error, not a hang; the context
+    keeps working afterwards and shapes may change freely between calls (graph cache, lanes)."""
+    from mcmc_ref_hip import _ffi, synth
+    x = synth.c1_model(4, 600, 2, seed=5)
+    t = ctx.upload(x, "pcn")
+    try:
+        for _ in range(_ffi.MCR_MAX_INFLIGHT):
+            ctx.enqueue(t)
+        with pytest.raises(_ffi.McrError) as ei:
+            ctx.enqueue(t)
+        assert ei.value.code == _ffi.MCR_EINVAL
+        ctx.wait()
+        exp = oracle.summarize(x, "pcn")
+        for shape in [(4, 600, 2), (4, 300, 2), (4, 600, 1), (4, 600, 2)]:
+            C, N, P = shape
+            y = np.ascontiguousarray(x[:P, :, :N])
+            check_summary(ctx.summarize(y, "pcn"), oracle.summarize(y, "pcn"), what=f"reuse{shape}")
+        check_summary(ctx.summarize(t), exp, what="reuse-dev")
+    finally:
+        t.free()
