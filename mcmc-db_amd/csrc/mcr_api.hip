@@ -28,12 +28,12 @@ constexpr int kMaxGridY = 65535;
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
-    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma"};
+    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -281,6 +281,7 @@ struct PipeIn {
     double* chstate;     // [pc][2][C][kChState]
     double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products 64..511
     i64 nstage;          // longest chain prefix the segment grid has to cover
+    double* ztab;        // [2M] z of every possible tie run (shared by all parameters of the call)
     double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
     u32* cut;            // [pc][B+1][ntiles]
     u32* boff;           // [pc][B+1]
@@ -328,6 +329,9 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
 {
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
+    // 0. z lookup table of this M (tiny; the rank kernels read it instead of evaluating Phi^-1 per draw)
+    if (a.do_diag)
+        LAUNCH(ctx, K_ZTABLE, k_ztable, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, a.ztab, M);
     // 1. tile sort (+ moment partials, + regular samples when a tile is already a run)
     const bool bucket = a.bk_B > 0;
     LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<kSortNT, kSortVT>), dim3((unsigned)a.ntiles, py), dim3(kSortNT),
@@ -342,7 +346,7 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
     for (i64 R = kTile; R < Rstop; R *= 2) {
         LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-               (const i64*)nullptr, (double*)nullptr, (double*)nullptr);
+               (const i64*)nullptr, (double*)nullptr, (double*)nullptr, (const double*)nullptr);
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
@@ -361,7 +365,7 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,
                (const double*)kin, (const u32*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
-               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc, a.bk_R);
+               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc, a.bk_R, (const double*)a.ztab);
         std::swap(kin, kout);
         std::swap(iin, iout);
         ranked = true;
@@ -390,12 +394,12 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)
         if (!ranked)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
-                   (const double*)kin, (const u32*)iin, M, a.zb, a.rank_b);
+                   (const double*)kin, (const u32*)iin, M, a.zb, a.rank_b, (const double*)a.ztab);
         // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
         LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3((unsigned)((pc + 7) / 8 * 8) * nblk),
                dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
-               (const i64*)a.split, a.zt, a.rank_t);
+               (const i64*)a.split, a.zt, a.rank_t, (const double*)a.ztab);
         // 7. R-hat + ESS
         if (a.C >= 2) {
             const int rc = launch_diag(ctx, a);
@@ -522,7 +526,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     if (!s.trivial_nan) {
         const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
         const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
-        const size_t slack = 32 * 256;
+        const size_t slack = 32 * 256 + (size_t)2 * M * 8;     // + the z table (once per call, not per parameter)
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
@@ -559,6 +563,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.state = cv.take<double>((size_t)pc * 2 * 4);
                 }
                 a.nstage = N > 0 ? N : 1;
+                a.ztab = cv.take<double>((size_t)2 * M);
                 a.samp = cv.take<double>((size_t)pc * (wp.ntiles + 16) * 64);
                 a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
@@ -931,7 +936,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         if (len >= 2 && len / 2 + nh > nstage) nstage = len / 2 + nh;
     }
     const WsPlan wp = plan_ws(M, C, true, want_rank, nstage);
-    const size_t slack = 32 * 256;
+    const size_t slack = 32 * 256 + (size_t)2 * M * 8;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
@@ -957,6 +962,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.state = cv.take<double>(8);
     }
     a.nstage = nstage;
+    a.ztab = cv.take<double>((size_t)2 * M);
     a.samp = cv.take<double>((size_t)(wp.ntiles + 16) * 64);
     a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));

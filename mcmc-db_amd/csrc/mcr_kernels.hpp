@@ -51,6 +51,22 @@ __device__ __forceinline__ bool xcd_map(i64 P, int nb, i64& p, int& blk)
 }
 
 // ------------------------------------------------------------------------------------------------
+// z lookup table.  A draw's z depends only on its tie run [s, e) and M:
+//     rank = (s + 1 + e) / 2,   z = Phi^-1((rank - 0.5) / M)          (diagnostics.py:117,130-131)
+// so z is a function of the integer n2 = s + e in [1, 2M-1] alone -- the same for every parameter
+// of the model.  One tiny launch evaluates it for all 2M values (same operations, hence the same
+// bits as evaluating it per draw); the rank kernels then replace two fp64 divides and two degree-7
+// rational polynomials per draw by one 8-byte read of an L2-resident table.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ztable(double* __restrict__ ztab, i64 M)
+{
+    const i64 n2 = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (n2 >= 2 * M) return;
+    const double r = (double)(n2 + 1) / 2.0;
+    ztab[n2] = (n2 >= 1) ? inv_cdf((r - 0.5) / (double)M) : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ingest: arbitrary element strides / f32 -> X[p][c*N + t] f64.
 // rows variant: lanes run along t (coalesced when stride_n == 1).
 // ------------------------------------------------------------------------------------------------
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
                                               double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                               i64 R, const double* __restrict__ res, i64 P,
                                               const i64* __restrict__ split, double* __restrict__ z,
-                                              double* __restrict__ rank_out)
+                                              double* __restrict__ rank_out, const double* __restrict__ ztab)
 {
     constexpr int OB = NT * VT;
     constexpr int TP = OB + OB / 16;
@@ -564,10 +580,9 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
             i64 gs = d0 + rs[i], ge = d0 + re[i];
             if (ext0 && v == vfirst) gs = gfirst;
             if (ext1 && v == vlast) ge = glast;
-            const double r = (double)(gs + 1 + ge) / 2.0;
             const u32 t = sidx[pos16(e)];
-            z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
-            if (rank_out) rank_out[p * M + t] = r;
+            z[p * M + t] = ztab[gs + ge];
+            if (rank_out) rank_out[p * M + t] = (double)(gs + 1 + ge) / 2.0;
         }
     }
 }
@@ -694,7 +709,8 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
                                                       double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                                       int k, int B, const u32* __restrict__ cut,
                                                       const u32* __restrict__ boff, double* __restrict__ z,
-                                                      double* __restrict__ rank_out, i64 P, i64 R)
+                                                      double* __restrict__ rank_out, i64 P, i64 R,
+                                                      const double* __restrict__ ztab)
 {
     constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -813,10 +829,9 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             i64 gs = obase + rs[i], ge = obase + re[i];
             if (ext0 && v == vfirst) gs = sedge[0];
             if (ext1 && v == vlast) ge = sedge[3];
-            const double r = (double)(gs + 1 + ge) / 2.0;
             const u32 t = sidx[pos16(e)];
-            z[p * M + t] = inv_cdf((r - 0.5) / (double)M);
-            if (rank_out) rank_out[p * M + t] = r;
+            z[p * M + t] = ztab[gs + ge];
+            if (rank_out) rank_out[p * M + t] = (double)(gs + 1 + ge) / 2.0;
         }
     }
 }
@@ -858,7 +873,8 @@ __global__ void k_order_stats(const double* __restrict__ keys, i64 M, i64 P, QAr
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
                                                 const u32* __restrict__ idx, i64 M,
-                                                double* __restrict__ z, double* __restrict__ rank_out)
+                                                double* __restrict__ z, double* __restrict__ rank_out,
+                                                const double* __restrict__ ztab)
 {
     const i64 p = blockIdx.y;
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -888,11 +904,9 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
         }
         e = lo + 1;
     }
-    const double r = (double)(s + 1 + e) / 2.0;
-    const double pr = (r - 0.5) / (double)M;
     const u32 t = idx[p * M + i];
-    z[p * M + t] = inv_cdf(pr);
-    if (rank_out) rank_out[p * M + t] = r;
+    z[p * M + t] = ztab[s + e];
+    if (rank_out) rank_out[p * M + t] = (double)(s + 1 + e) / 2.0;
 }
 
 // ------------------------------------------------------------------------------------------------
