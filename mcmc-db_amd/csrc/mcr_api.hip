@@ -255,8 +255,8 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
         }
     }
     w.per_param = (size_t)(w.ntiles + 16) * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.bk_k + 1) * 4 + 16 +
-                  (size_t)M * (8 + 4) * 2 + (size_t)M * 8 * 2 + (ingest ? (size_t)M * 8 : 0) +
-                  (ranks ? (size_t)M * 16 : 0) + (size_t)w.ntiles * 32 + 8 +
+                  (size_t)M * (8 + 4) * 2 + (size_t)M * 4 * 2 + (ingest ? (size_t)M * 8 : 0) +
+                  (ranks ? (size_t)M * 32 + 1024 : 0) + (size_t)w.ntiles * 32 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) *
                       ((size_t)((nstage + kSeg - 1) / kSeg + 1) * (kSegRec + 64 * kMoreBlocks) + kChState) * 8 +
                   8 + 64;
@@ -272,7 +272,8 @@ struct PipeIn {
     QArgs q;
     double* d_res;       // chunk's result table, stride pc
     // carved buffers
-    double *kA, *kB, *zb, *zt, *part, *rank_b, *rank_t;
+    double *kA, *kB, *part;
+    u32 *zb, *zt;        // rank codes n2 of every draw in time order (z = ztab[n2], rank = (n2 + 1) / 2)
     u32 *iA, *iB;
     i64* split;
     double* rec;         // [pc][2][C][nseg][kSegRec] first-pass segment records
@@ -302,22 +303,27 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     const unsigned pk = (unsigned)(2 * a.pc);
     if (small) {
         LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<128, 1024, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
-               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
+               (const unsigned*)nullptr, a.rec);
     } else {
         LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<256, kSeg, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
-               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)nullptr, a.rec);
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
+               (const unsigned*)nullptr, a.rec);
     }
-    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, a.zb, a.zt, a.M,
-           a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate);
+    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, (const u32*)a.zb,
+           (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate);
     // continuation for pairs whose first negative rho lies beyond lag 63 (others exit at once)
     if (small) {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
-               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
+               (const unsigned*)a.more, a.rec2);
     } else {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<256, kSeg, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
-               a.zb, a.zt, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const unsigned*)a.more, a.rec2);
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
+               (const unsigned*)a.more, a.rec2);
     }
-    LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(256), (size_t)2 * a.C * 8, a.zb, a.zt, a.M, a.d_off, a.C,
+    LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(256), (size_t)2 * a.C * 8, (const u32*)a.zb,
+           (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, (const double*)a.state,
            (const double*)a.chstate, a.d_res, a.pc);
     return MCR_OK;
@@ -346,7 +352,7 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
     for (i64 R = kTile; R < Rstop; R *= 2) {
         LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-               (const i64*)nullptr, (double*)nullptr, (double*)nullptr, (const double*)nullptr);
+               (const i64*)nullptr, (u32*)nullptr);
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
@@ -365,7 +371,7 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,
                (const double*)kin, (const u32*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
-               (const u32*)a.boff, a.do_diag ? a.zb : (double*)nullptr, a.rank_b, pc, a.bk_R, (const double*)a.ztab);
+               (const u32*)a.boff, a.do_diag ? a.zb : (u32*)nullptr, pc, a.bk_R);
         std::swap(kin, kout);
         std::swap(iin, iout);
         ranked = true;
@@ -394,12 +400,12 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)
         if (!ranked)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
-                   (const double*)kin, (const u32*)iin, M, a.zb, a.rank_b, (const double*)a.ztab);
+                   (const double*)kin, (const u32*)iin, M, a.zb);
         // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
         LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3((unsigned)((pc + 7) / 8 * 8) * nblk),
                dim3(kSortNT), kSortLds,
                (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
-               (const i64*)a.split, a.zt, a.rank_t, (const double*)a.ztab);
+               (const i64*)a.split, a.zt);
         // 7. R-hat + ESS
         if (a.C >= 2) {
             const int rc = launch_diag(ctx, a);
@@ -497,7 +503,7 @@ int check_common(mcr_ctx* ctx, const void* draws, int dtype, i64 C, i64 N, i64 P
     if (C < min_chains)
         return fail(ctx, MCR_EMINCHAINS, "diagnostics require at least %d chains; got %lld chain(s)", min_chains, C);
     if (C > kMaxChains) return fail(ctx, MCR_EINVAL, "at most %d chains are supported; got %lld", kMaxChains, C);
-    if (C * N >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "C*N must be < 2^32");
+    if (C * N >= (i64)0x7FFFFFFFll) return fail(ctx, MCR_EINVAL, "C*N must be < 2^31");   // 2M-1 rank codes in u32
     if (!draws && C * N * P > 0) return fail(ctx, MCR_EINVAL, "draws is NULL");
     return MCR_OK;
 }
@@ -551,7 +557,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.ntiles = wp.ntiles;
                 a.kA = cv.take<double>((size_t)pc * M); a.kB = cv.take<double>((size_t)pc * M);
                 a.iA = cv.take<u32>((size_t)pc * M);    a.iB = cv.take<u32>((size_t)pc * M);
-                a.zb = cv.take<double>((size_t)pc * M); a.zt = cv.take<double>((size_t)pc * M);
+                a.zb = cv.take<u32>((size_t)pc * M); a.zt = cv.take<u32>((size_t)pc * M);
                 a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
                 a.split = cv.take<i64>((size_t)pc);
                 {
@@ -568,7 +574,6 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
                 a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
-                a.rank_b = a.rank_t = nullptr;
                 a.do_diag = do_diag;
                 if (ingest) {
                     double* X = cv.take<double>((size_t)pc * M);
@@ -914,7 +919,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     if (C > 0 && !chain_off) return fail(ctx, MCR_EINVAL, "chain_off is NULL");
     if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_diagnose_chains with summaries in flight");
     const i64 M = C > 0 ? chain_off[C] : 0;
-    if (M < 0 || M >= (i64)0xFFFFFFFFll) return fail(ctx, MCR_EINVAL, "pooled length out of range");
+    if (M < 0 || M >= (i64)0x7FFFFFFFll) return fail(ctx, MCR_EINVAL, "pooled length out of range");
     i64 n = 0, nh = 0;
     bool have_h = false;
     for (int c = 0; c < C; ++c) {
@@ -929,13 +934,13 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     s.trivial_nan = (M == 0);
     if (s.trivial_nan) { s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1; return wait_impl(ctx); }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool want_rank = rank_bulk || rank_tail;
+    const bool want_dbg = z_bulk || z_tail || rank_bulk || rank_tail;
     i64 nstage = n > 0 ? n : 1;
     for (int c = 0; c < C; ++c) {
         const i64 len = chain_off[c + 1] - chain_off[c];
         if (len >= 2 && len / 2 + nh > nstage) nstage = len / 2 + nh;
     }
-    const WsPlan wp = plan_ws(M, C, true, want_rank, nstage);
+    const WsPlan wp = plan_ws(M, C, true, want_dbg, nstage);
     const size_t slack = 32 * 256 + (size_t)2 * M * 8;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
@@ -950,7 +955,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.M = M; a.pc = 1; a.C = C; a.d_off = s.d_off; a.n = n; a.nh = nh; a.q.nq = 0; a.ntiles = wp.ntiles;
     a.kA = cv.take<double>((size_t)M); a.kB = cv.take<double>((size_t)M);
     a.iA = cv.take<u32>((size_t)M);    a.iB = cv.take<u32>((size_t)M);
-    a.zb = cv.take<double>((size_t)M); a.zt = cv.take<double>((size_t)M);
+    a.zb = cv.take<u32>((size_t)M); a.zt = cv.take<u32>((size_t)M);
     a.part = cv.take<double>((size_t)wp.ntiles * 4);
     a.split = cv.take<i64>(1);
     {
@@ -968,8 +973,8 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));
     a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
     double* X = cv.take<double>((size_t)M);
-    a.rank_b = want_rank ? cv.take<double>((size_t)M) : nullptr;
-    a.rank_t = want_rank ? cv.take<double>((size_t)M) : nullptr;
+    double* dbg[4] = {nullptr, nullptr, nullptr, nullptr};     // z_bulk, z_tail, rank_bulk, rank_tail (decoded codes)
+    if (want_dbg) for (int i = 0; i < 4; ++i) dbg[i] = cv.take<double>((size_t)M);
     HIP_TRY(ctx, hipMemcpyAsync(X, pooled, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, ctx->stream));
     a.X = X;
     a.d_res = s.d_res;
@@ -980,10 +985,18 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     auto back = [&](double* dst, const double* srcp) -> hipError_t {
         return dst ? hipMemcpyAsync(dst, srcp, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
     };
-    HIP_TRY(ctx, back(z_bulk, a.zb));
-    HIP_TRY(ctx, back(z_tail, a.zt));
-    HIP_TRY(ctx, back(rank_bulk, a.rank_b));
-    HIP_TRY(ctx, back(rank_tail, a.rank_t));
+    if (want_dbg) {
+        const unsigned nb = (unsigned)((M + 255) / 256);
+        hipLaunchKernelGGL(k_decode_codes, dim3(nb), dim3(256), 0, ctx->stream, (const u32*)a.zb, (const double*)a.ztab, M,
+                           z_bulk ? dbg[0] : (double*)nullptr, rank_bulk ? dbg[2] : (double*)nullptr);
+        hipLaunchKernelGGL(k_decode_codes, dim3(nb), dim3(256), 0, ctx->stream, (const u32*)a.zt, (const double*)a.ztab, M,
+                           z_tail ? dbg[1] : (double*)nullptr, rank_tail ? dbg[3] : (double*)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, back(z_bulk, dbg[0]));
+    HIP_TRY(ctx, back(z_tail, dbg[1]));
+    HIP_TRY(ctx, back(rank_bulk, dbg[2]));
+    HIP_TRY(ctx, back(rank_tail, dbg[3]));
     s.busy = true; ctx->order.push_back(0); ctx->n_inflight = 1;
     return wait_impl(ctx);
 }

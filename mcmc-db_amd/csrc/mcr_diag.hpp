@@ -35,6 +35,14 @@ enum SegField { SG_S = 64, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
 
 __device__ __forceinline__ i64 pos8(i64 j) { return j + ((j >> 3) << 1); }
 
+// Rank code -> z.  The clamp only matters for tensors the call is about to reject (NaN draws break
+// the sort's ordering, so some codes may be stale workspace bytes): it keeps the read inside the table.
+__device__ __forceinline__ double zdec(const double* __restrict__ ztab, u32 code, i64 M)
+{
+    const u32 cmax = (u32)(2 * M - 1);
+    return ztab[code < cmax ? code : cmax];
+}
+
 // Three deterministic block sums with one barrier pair.  `red` holds 3 * NT/64 doubles.
 template <int NT>
 __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red)
@@ -110,10 +118,10 @@ __device__ __forceinline__ void seg_products(const double* __restrict__ A, const
 // FIRST == false: lags 64..64+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
 // grid (nseg, C, 2 * P); blockIdx.z = 2 * p + kind.
 template <int NT, int SEG, bool FIRST>
-__global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, const double* __restrict__ zt,
-                                                 i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
-                                                 int nseg, const unsigned* __restrict__ more,
-                                                 double* __restrict__ rec)
+__global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                 const double* __restrict__ ztab, i64 M,
+                                                 const i64* __restrict__ off, int C, i64 n, i64 nh, int nseg,
+                                                 const unsigned* __restrict__ more, double* __restrict__ rec)
 {
     constexpr int NW = NT / kWave;
     constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + 80) / 8 * 10;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
     const i64 pk = blockIdx.z, p = pk >> 1;
     const int kind = (int)(pk & 1);
     if (!FIRST && more[pk] == 0u) return;
-    const double* zc = (kind ? zt : zb) + p * M + off[c];
+    const u32* zc = (kind ? zt : zb) + p * M + off[c];     // rank codes; z = ztab[code]
     const i64 nc = off[c + 1] - off[c], hc = nc / 2;
     const i64 hspan = (hc > 0) ? hc + nh : 0;
     const i64 nload = (n > hspan) ? n : hspan;          // <= nc
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int j = u * NT + tid;
-            v[u] = (j < r_load) ? zc[s0 + j] : 0.0;
+            v[u] = (j < r_load) ? zdec(ztab, zc[s0 + j], M) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
@@ -194,12 +202,12 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const double* __restrict__ zb, 
             for (int j = tid; j < 64 * kMoreBlocks; j += NT) r[j] = 0.0;
             return;
         }
-        for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+        for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
         for (int blk = 0; blk < kMoreBlocks; ++blk) {
             const i64 lb = 64 + 64 * blk;
             __syncthreads();
-            for (int j = tid; j < SEG + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zc[g] : 0.0; }
+            for (int j = tid; j < SEG + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
             __syncthreads();
             seg_products<NT>(sA, sB, seglen, tot, wred);
             if (tid < 64) r[blk * 64 + tid] = tot[tid];
@@ -222,8 +230,9 @@ __device__ __forceinline__ double wave_excl_scan(double v, double& total)
 constexpr int kChState = 6;   // mean, S, constant flag, head(64), tail(64), -
 
 // One wave per (parameter, kind).  grid (P, 2), block 64.
-__global__ __launch_bounds__(64) void k_diag_combine(const double* __restrict__ zb, const double* __restrict__ zt,
-                                                     i64 M, const i64* __restrict__ off, int C, i64 n, i64 nh,
+__global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                     const double* __restrict__ ztab, i64 M,
+                                                     const i64* __restrict__ off, int C, i64 n, i64 nh,
                                                      int nseg, const double* __restrict__ rec,
                                                      double* __restrict__ res, i64 P, unsigned* __restrict__ more,
                                                      double* __restrict__ state, double* __restrict__ chstate)
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(64) void k_diag_combine(const double* __restrict__ 
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
-    const double* z = (kind ? zt : zb) + p * M;
+    const u32* z = (kind ? zt : zb) + p * M;
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
@@ -255,10 +264,10 @@ __global__ __launch_bounds__(64) void k_diag_combine(const double* __restrict__ 
         }
         const bool constant = !(vmin < vmax);
         const double m = (n > 0) ? S / (double)n : 0.0;
-        const double* zc = z + off[c];
+        const u32* zc = z + off[c];
         double th, tt;
-        const double head = wave_excl_scan((lane < n) ? zc[lane] : 0.0, th);            // sum_{i<l} z_i
-        const double tail = wave_excl_scan((lane < n) ? zc[n - 1 - lane] : 0.0, tt);    // sum_{i>=n-l} z_i
+        const double head = wave_excl_scan((lane < n) ? zdec(ztab, zc[lane], M) : 0.0, th);            // sum_{i<l} z_i
+        const double tail = wave_excl_scan((lane < n) ? zdec(ztab, zc[n - 1 - lane], M) : 0.0, tt);    // sum_{i>=n-l} z_i
         if (!constant && lane < n)
             covsum += Pl - m * ((S - tail) + (S - head)) + (double)(n - lane) * m * m;
         if (lane == 0) {
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(64) void k_diag_combine(const double* __restrict__ 
 
 // Continuation for flagged pairs: lags 64..255 from the second k_acov_seg pass, then (very sticky
 // chains only) a direct deviation-product loop over L2 from lag 256.  grid (P, 2), block 256.
-__global__ __launch_bounds__(256) void k_diag_combine2(const double* __restrict__ zb,
-                                                       const double* __restrict__ zt, i64 M,
+__global__ __launch_bounds__(256) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                       const double* __restrict__ ztab, i64 M,
                                                        const i64* __restrict__ off, int C, i64 n, int nseg,
                                                        const double* __restrict__ rec2,
                                                        const unsigned* __restrict__ more,
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void k_diag_combine2(const double* __restrict_
     __shared__ double wred[4 * 64];
     __shared__ double ctl[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const double* z = (kind ? zt : zb) + p * M;
+    const u32* z = (kind ? zt : zb) + p * M;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
     double rho_sum = state[pk * 4 + 0];
@@ -396,10 +405,10 @@ __global__ __launch_bounds__(256) void k_diag_combine2(const double* __restrict_
             double covsum = 0.0;
             for (int c = 0; c < C; ++c) {
                 const double* cs = chstate + (pk * C + c) * kChState;
-                const double* zc = z + off[c];
+                const u32* zc = z + off[c];
                 double th, tt;
-                const double hx = wave_excl_scan((lb + lane < n) ? zc[lb + lane] : 0.0, th);
-                const double tx = wave_excl_scan((lb + lane < n) ? zc[n - 1 - (lb + lane)] : 0.0, tt);
+                const double hx = wave_excl_scan((lb + lane < n) ? zdec(ztab, zc[lb + lane], M) : 0.0, th);
+                const double tx = wave_excl_scan((lb + lane < n) ? zdec(ztab, zc[n - 1 - (lb + lane)], M) : 0.0, tt);
                 const double head = hb[c] + hx, tail = tb[c] + tx;   // sums of the first / last (lb + lane) draws
                 if (lane == 0) { hb[c] += th; tb[c] += tt; }
                 if (cs[2] != 0.0) continue;                       // constant chain: zero deviations
@@ -433,8 +442,8 @@ __global__ __launch_bounds__(256) void k_diag_combine2(const double* __restrict_
             const double* cs = chstate + (pk * C + c) * kChState;
             if (cs[2] != 0.0) continue;
             const double m = cs[0];
-            const double* zc = z + off[c];
-            for (i64 i = w; i + lag < n; i += 4) acc = fma(zc[i] - m, zc[i + lag] - m, acc);
+            const u32* zc = z + off[c];
+            for (i64 i = w; i + lag < n; i += 4) acc = fma(zdec(ztab, zc[i], M) - m, zdec(ztab, zc[i + lag], M) - m, acc);
         }
         __syncthreads();
         wred[w * 64 + lane] = acc;

@@ -55,8 +55,10 @@ __device__ __forceinline__ bool xcd_map(i64 P, int nb, i64& p, int& blk)
 //     rank = (s + 1 + e) / 2,   z = Phi^-1((rank - 0.5) / M)          (diagnostics.py:117,130-131)
 // so z is a function of the integer n2 = s + e in [1, 2M-1] alone -- the same for every parameter
 // of the model.  One tiny launch evaluates it for all 2M values (same operations, hence the same
-// bits as evaluating it per draw); the rank kernels then replace two fp64 divides and two degree-7
-// rational polynomials per draw by one 8-byte read of an L2-resident table.
+// bits as evaluating it per draw).  The rank kernels therefore scatter only the 4-byte CODE n2 of
+// each draw to time order (half the bytes and half the L2 footprint of scattering z itself: the
+// scattered stores are the expensive part), and the consumers (k_acov_seg,
+// k_diag_combine*) turn codes into z with one read of this L2-resident table.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ztable(double* __restrict__ ztab, i64 M)
 {
@@ -64,6 +66,18 @@ __global__ __launch_bounds__(256) void k_ztable(double* __restrict__ ztab, i64 M
     if (n2 >= 2 * M) return;
     const double r = (double)(n2 + 1) / 2.0;
     ztab[n2] = (n2 >= 1) ? inv_cdf((r - 0.5) / (double)M) : 0.0;
+}
+
+// Codes -> z and average ranks in time order (debug outputs of mcr_diagnose_chains only).
+__global__ __launch_bounds__(256) void k_decode_codes(const u32* __restrict__ code, const double* __restrict__ ztab,
+                                                      i64 n, double* __restrict__ z, double* __restrict__ rank)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32 c = code[i];
+    if ((i64)c > 2 * n - 1) c = (u32)(2 * n - 1);
+    if (z) z[i] = ztab[c];
+    if (rank) rank[i] = (double)((i64)c + 1) / 2.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,8 +455,7 @@ template <int NT, int VT, bool FOLD>
 __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
                                               double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                               i64 R, const double* __restrict__ res, i64 P,
-                                              const i64* __restrict__ split, double* __restrict__ z,
-                                              double* __restrict__ rank_out, const double* __restrict__ ztab)
+                                              const i64* __restrict__ split, u32* __restrict__ z)
 {
     constexpr int OB = NT * VT;
     constexpr int TP = OB + OB / 16;
@@ -580,9 +593,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
             i64 gs = d0 + rs[i], ge = d0 + re[i];
             if (ext0 && v == vfirst) gs = gfirst;
             if (ext1 && v == vlast) ge = glast;
-            const u32 t = sidx[pos16(e)];
-            z[p * M + t] = ztab[gs + ge];
-            if (rank_out) rank_out[p * M + t] = (double)(gs + 1 + ge) / 2.0;
+            z[p * M + sidx[pos16(e)]] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
@@ -708,9 +719,8 @@ __global__ __launch_bounds__(256) void k_sample_runs(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
                                                       double* __restrict__ kout, u32* __restrict__ iout, i64 M,
                                                       int k, int B, const u32* __restrict__ cut,
-                                                      const u32* __restrict__ boff, double* __restrict__ z,
-                                                      double* __restrict__ rank_out, i64 P, i64 R,
-                                                      const double* __restrict__ ztab)
+                                                      const u32* __restrict__ boff, u32* __restrict__ z, i64 P,
+                                                      i64 R)
 {
     constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -829,9 +839,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             i64 gs = obase + rs[i], ge = obase + re[i];
             if (ext0 && v == vfirst) gs = sedge[0];
             if (ext1 && v == vlast) ge = sedge[3];
-            const u32 t = sidx[pos16(e)];
-            z[p * M + t] = ztab[gs + ge];
-            if (rank_out) rank_out[p * M + t] = (double)(gs + 1 + ge) / 2.0;
+            z[p * M + sidx[pos16(e)]] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
@@ -872,9 +880,7 @@ __global__ void k_order_stats(const double* __restrict__ keys, i64 M, i64 P, QAr
 // loads and long tie runs cost O(log run).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
-                                                const u32* __restrict__ idx, i64 M,
-                                                double* __restrict__ z, double* __restrict__ rank_out,
-                                                const double* __restrict__ ztab)
+                                                const u32* __restrict__ idx, i64 M, u32* __restrict__ z)
 {
     const i64 p = blockIdx.y;
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -904,9 +910,7 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
         }
         e = lo + 1;
     }
-    const u32 t = idx[p * M + i];
-    z[p * M + t] = ztab[s + e];
-    if (rank_out) rank_out[p * M + t] = (double)(s + 1 + e) / 2.0;
+    z[p * M + idx[p * M + i]] = (u32)(s + e);   // code of the tie run: rank = (code + 1) / 2
 }
 
 // ------------------------------------------------------------------------------------------------
