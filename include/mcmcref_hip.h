@@ -194,6 +194,62 @@ int mcr_profile_get(mcr_ctx* ctx, mcr_kernel_time* out, int max, int* n);
 int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P,
                        uint64_t seed);
 
+/* ------------------------------------------------------------------------------------------------
+ * Parquet ingest: draws file -> device tensor.
+ * Replaces pq.read_table / pq.ParquetFile + to_numpy on the way into the statistics
+ * (src/mcmc_ref/store.py:79-95 open_draws, src/mcmc_ref/convert.py:61-65, backends_numpy.py:35):
+ * footer and page headers are parsed on the host, page payloads are Snappy-decompressed and
+ * PLAIN / RLE_DICTIONARY decoded by HIP kernels straight into device memory.
+ * Supported: flat schemas; INT32 / INT64 / FLOAT / DOUBLE columns, REQUIRED or OPTIONAL without
+ * nulls; UNCOMPRESSED / SNAPPY; data pages v1 and v2; any number of row groups and pages.
+ * Anything else fails with MCR_EINVAL and a message naming the feature.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mcr_parquet mcr_parquet;
+
+#define MCR_PQ_F64 0 /* out_dev is double[num_rows]  (ints and floats are converted to double) */
+#define MCR_PQ_I64 1 /* out_dev is int64_t[num_rows] (INT32 / INT64 columns only: chain, draw) */
+
+/* Physical types as in parquet.thrift (mcr_parquet_column_type). */
+#define MCR_PQ_BOOLEAN 0
+#define MCR_PQ_INT32 1
+#define MCR_PQ_INT64 2
+#define MCR_PQ_INT96 3
+#define MCR_PQ_FLOAT 4
+#define MCR_PQ_DOUBLE 5
+#define MCR_PQ_BYTE_ARRAY 6
+#define MCR_PQ_FIXED_LEN_BYTE_ARRAY 7
+
+typedef struct {
+    const mcr_parquet* file;
+    int column;    /* index into the file's (flat) schema */
+    int out_kind;  /* MCR_PQ_F64 or MCR_PQ_I64 */
+    void* out_dev; /* device pointer, num_rows 8-byte elements, rows in file order */
+} mcr_parquet_request;
+
+/* Parses the metadata of a Parquet file image held in host memory.  `bytes` must stay valid and
+ * unchanged until mcr_parquet_close (the image is not copied).  Needs no device: ctx may be NULL
+ * (the message of a failure is then read with mcr_last_error(NULL)). */
+int mcr_parquet_open(mcr_ctx* ctx, const void* bytes, size_t len, mcr_parquet** out);
+void mcr_parquet_close(mcr_parquet* f);
+int64_t mcr_parquet_num_rows(const mcr_parquet* f);
+int mcr_parquet_num_columns(const mcr_parquet* f);
+const char* mcr_parquet_column_name(const mcr_parquet* f, int column); /* NULL if out of range */
+int mcr_parquet_column_type(const mcr_parquet* f, int column);         /* -1 if out of range */
+/* Page table as parsed from the page headers (introspection / tests).  info[10] = {column, page
+ * type, value encoding, codec, payload file offset, compressed size, uncompressed size, values,
+ * first row, page index of the chunk's dictionary page or -1}. */
+int mcr_parquet_num_pages(const mcr_parquet* f);
+int mcr_parquet_page_info(const mcr_parquet* f, int page, int64_t* info);
+
+/* Decodes the requested columns (of one or many files) with ONE upload + two kernel launches;
+ * synchronous on return.  Requests may mix files, columns and output kinds. */
+int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs);
+
+/* dst[p][k] = src[p][order[k]]: puts rows that are not stored in (chain, draw) order into the
+ * order `_chains_from_table` produces (src/mcmc_ref/convert.py:150-161).  order is a host array. */
+int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t M, const int64_t* order,
+                        double* dst_dev);
+
 #ifdef __cplusplus
 }
 #endif

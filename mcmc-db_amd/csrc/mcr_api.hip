@@ -5,16 +5,21 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <new>
 #include <vector>
 
 #include "mcr_kernels.hpp"
 #include "mcr_diag.hpp"
 #include "mcr_ext.hpp"
+#include "mcr_parquet.hpp"
 
 using namespace mcr;
 
@@ -28,12 +33,13 @@ constexpr int kMaxGridY = 65535;
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
-    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable"};
+    "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable",
+    "k_pq_snappy", "k_pq_decode", "k_gather_rows"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -75,6 +81,10 @@ struct mcr_ctx {
     size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
     int lane = 0, n_lanes = 4;
     void* stage = nullptr; size_t stage_bytes = 0;  // device copy of host tensors (mcr_summarize)
+    // Parquet ingest (mcr_parquet_decode): uploaded column chunks, decompression scratch, page table + error word
+    void* pq_stage = nullptr; size_t pq_stage_bytes = 0;
+    void* pq_scratch = nullptr; size_t pq_scratch_bytes = 0;
+    void* pq_tab = nullptr; size_t pq_tab_bytes = 0;
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
     std::vector<int> order;  // busy slots in enqueue order
@@ -785,6 +795,9 @@ void mcr_free(mcr_ctx* ctx)
     ctx->lane_ws[0] = ctx->ws;
     for (void* w : ctx->lane_ws) if (w) hipFree(w);
     if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->pq_stage) hipFree(ctx->pq_stage);
+    if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
+    if (ctx->pq_tab) hipFree(ctx->pq_tab);
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
     delete ctx;
 }
@@ -1256,6 +1269,219 @@ int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int6
         LAUNCH(ctx, K_FILL, (k_fill_synth<float>), dim3((unsigned)blocks), dim3(256), 0, (float*)draws_dev, total,
                (i64)(C * N), (u64)seed);
     }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
+
+// ---- Parquet ingest (replaces pq.read_table at store.py:79-95 / convert.py:61-65) -----------
+
+struct mcr_parquet { mcr::pq::File f; };
+
+namespace {
+int ensure_buf(mcr_ctx* ctx, void** p, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return MCR_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*p) { hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = bytes + (bytes >> 2);
+    const hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) return fail(ctx, MCR_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    *cap = want;
+    return MCR_OK;
+}
+}  // namespace
+
+int mcr_parquet_open(mcr_ctx* ctx, const void* bytes, size_t len, mcr_parquet** out)
+{
+    if (!bytes || !out) return fail(ctx, MCR_EINVAL, "NULL argument");     // ctx may be NULL: parsing needs no device
+    mcr_parquet* f = new (std::nothrow) mcr_parquet();
+    if (!f) return fail(ctx, MCR_ENOMEM, "out of host memory");
+    bool ok = false;
+    try { ok = mcr::pq::open(f->f, bytes, len); }
+    catch (const std::exception& e) { f->f.error = std::string("host allocation failed: ") + e.what(); }
+    if (!ok) {
+        const int rc = fail(ctx, MCR_EINVAL, "parquet: %s", f->f.error.c_str());
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return MCR_OK;
+}
+
+void mcr_parquet_close(mcr_parquet* f) { delete f; }
+int64_t mcr_parquet_num_rows(const mcr_parquet* f) { return f ? f->f.num_rows : -1; }
+int mcr_parquet_num_columns(const mcr_parquet* f) { return f ? (int)f->f.cols.size() : -1; }
+const char* mcr_parquet_column_name(const mcr_parquet* f, int col)
+{
+    return (f && col >= 0 && col < (int)f->f.cols.size()) ? f->f.cols[col].name.c_str() : nullptr;
+}
+int mcr_parquet_column_type(const mcr_parquet* f, int col)
+{
+    return (f && col >= 0 && col < (int)f->f.cols.size()) ? f->f.cols[col].type : -1;
+}
+
+int mcr_parquet_num_pages(const mcr_parquet* f) { return f ? (int)f->f.pages.size() : -1; }
+int mcr_parquet_page_info(const mcr_parquet* f, int page, int64_t* info)
+{
+    if (!f || !info || page < 0 || page >= (int)f->f.pages.size()) return MCR_EINVAL;
+    const mcr::pq::Page& p = f->f.pages[page];
+    info[0] = p.col; info[1] = p.kind; info[2] = p.encoding; info[3] = p.codec; info[4] = (int64_t)p.payload_off;
+    info[5] = p.comp_size; info[6] = p.uncomp_size; info[7] = p.num_values; info[8] = (int64_t)p.row_off; info[9] = p.dict;
+    return MCR_OK;
+}
+
+int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs)
+{
+    namespace pq = mcr::pq;
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (n_reqs < 0 || (n_reqs > 0 && !reqs)) return fail(ctx, MCR_EINVAL, "bad request list");
+    if (n_reqs == 0) return MCR_OK;
+    struct Span { const pq::File* f; u64 start, end; size_t stage_off; };
+    std::vector<Span> spans;
+    std::vector<pq::PageDev> tab;
+    std::vector<int> l_snappy, l_decode;
+    try {
+        // 1. byte spans to upload: the column chunks of the requested columns, merged when (nearly) adjacent
+        for (int r = 0; r < n_reqs; ++r) {
+            const mcr_parquet_request& q = reqs[r];
+            if (!q.file) return fail(ctx, MCR_EINVAL, "request %d: file is NULL", r);
+            const pq::File& f = q.file->f;
+            if (q.column < 0 || q.column >= (int)f.cols.size()) return fail(ctx, MCR_EINVAL, "request %d: column %d out of range", r, q.column);
+            const pq::Column& col = f.cols[q.column];
+            if (col.type != pq::T_INT32 && col.type != pq::T_INT64 && col.type != pq::T_FLOAT && col.type != pq::T_DOUBLE)
+                return fail(ctx, MCR_EINVAL, "parquet: column '%s' has physical type %d; only INT32, INT64, FLOAT and DOUBLE columns are decoded", col.name.c_str(), col.type);
+            if (q.out_kind != MCR_PQ_F64 && q.out_kind != MCR_PQ_I64) return fail(ctx, MCR_EINVAL, "request %d: bad out_kind %d", r, q.out_kind);
+            if (q.out_kind == MCR_PQ_I64 && col.type != pq::T_INT32 && col.type != pq::T_INT64)
+                return fail(ctx, MCR_EINVAL, "parquet: column '%s' is not an integer column", col.name.c_str());
+            if (f.num_rows > 0 && !q.out_dev) return fail(ctx, MCR_EINVAL, "request %d: out_dev is NULL", r);
+            for (const pq::Chunk& ch : f.chunks)
+                if (ch.col == q.column && ch.end > ch.start) spans.push_back(Span{&f, ch.start, ch.end, 0});
+        }
+        std::sort(spans.begin(), spans.end(), [](const Span& a, const Span& b) {
+            return a.f != b.f ? std::less<const pq::File*>()(a.f, b.f) : a.start < b.start; });
+        std::vector<Span> merged;
+        for (const Span& s : spans) {
+            if (!merged.empty() && merged.back().f == s.f && s.start <= merged.back().end + 4096) {
+                if (s.end > merged.back().end) merged.back().end = s.end;
+            } else merged.push_back(s);
+        }
+        size_t stage_total = 0;
+        for (Span& s : merged) { s.stage_off = align_up(stage_total, 256); stage_total = s.stage_off + (size_t)(s.end - s.start); }
+        auto stage_of = [&](const pq::File* f, u64 off) -> size_t {
+            for (const Span& s : merged) if (s.f == f && off >= s.start && off < s.end) return s.stage_off + (size_t)(off - s.start);
+            return (size_t)-1;
+        };
+        // 2. page table
+        size_t scratch_total = 0;
+        for (int r = 0; r < n_reqs; ++r) {
+            const mcr_parquet_request& q = reqs[r];
+            const pq::File& f = q.file->f;
+            const pq::Column& col = f.cols[q.column];
+            const u32 es = (col.type == pq::T_INT64 || col.type == pq::T_DOUBLE) ? 8 : 4;
+            for (const pq::Chunk& ch : f.chunks) {
+                if (ch.col != q.column) continue;
+                int dict_idx = -1;
+                for (int k = 0; k < ch.n_pages; ++k) {
+                    const pq::Page& pg = f.pages[(size_t)ch.first_page + k];
+                    if (pg.codec != pq::CODEC_NONE && pg.codec != pq::CODEC_SNAPPY)
+                        return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses compression codec %d; only UNCOMPRESSED and SNAPPY are decoded", col.name.c_str(), pg.codec);
+                    pq::PageDev d; memset(&d, 0, sizeof(d));
+                    const bool v2 = pg.kind == pq::PAGE_DATA_V2;
+                    const u32 lvl = v2 ? pg.rep_bytes + pg.def_bytes : 0;
+                    const bool comp = pg.codec == pq::CODEC_SNAPPY && (!v2 || pg.v2_compressed);
+                    if (pg.uncomp_size < lvl) return fail(ctx, MCR_EINVAL, "parquet: v2 page smaller than its levels");
+                    d.src_off = stage_of(&f, pg.payload_off);
+                    if (pg.comp_size > 0 && d.src_off == (u64)(size_t)-1) return fail(ctx, MCR_EINVAL, "parquet: page outside its column chunk");
+                    d.comp_size = pg.comp_size - lvl; d.uncomp_size = pg.uncomp_size - lvl;
+                    d.num_values = pg.num_values; d.lvl_bytes = lvl; d.def_bytes = v2 ? pg.def_bytes : 0;
+                    d.kind = (unsigned char)pg.kind; d.compressed = comp ? 1 : 0; d.phys_type = (unsigned char)col.type;
+                    d.max_def = (unsigned char)((v2 && pg.def_bytes == 0) ? 0 : col.max_def);   // v2 without level bytes: all defined
+                    d.out_kind = (unsigned char)q.out_kind;
+                    d.dict_page = -1;
+                    if (v2 && pg.rep_bytes) return fail(ctx, MCR_EINVAL, "parquet: repetition levels in a flat column");
+                    if (!comp && d.comp_size != d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: uncompressed page with differing sizes");
+                    if (comp) { d.dst_off = align_up(scratch_total, 16); scratch_total = (size_t)d.dst_off + d.uncomp_size + 16; }
+                    if (pg.kind == pq::PAGE_DICT) {
+                        if (pg.encoding != pq::ENC_PLAIN && pg.encoding != pq::ENC_PLAIN_DICT)
+                            return fail(ctx, MCR_EINVAL, "parquet: dictionary page encoding %d is not supported", pg.encoding);
+                        if ((u64)pg.num_values * es > d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: dictionary page shorter than its entries");
+                        d.encoding = pq::ENC_PLAIN;
+                        dict_idx = (int)tab.size();
+                    } else {
+                        if (pg.encoding == pq::ENC_PLAIN) d.encoding = pq::ENC_PLAIN;
+                        else if (pg.encoding == pq::ENC_RLE_DICT || pg.encoding == pq::ENC_PLAIN_DICT) {
+                            if (pg.dict < 0 || dict_idx < 0) return fail(ctx, MCR_EINVAL, "parquet: dictionary-encoded page without a dictionary page");
+                            d.encoding = pq::ENC_RLE_DICT; d.dict_page = dict_idx; d.dict_count = pg.dict_count;
+                        } else
+                            return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses value encoding %d; only PLAIN and RLE_DICTIONARY are decoded", col.name.c_str(), pg.encoding);
+                        d.out = q.out_dev; d.out_off = pg.row_off;
+                        l_decode.push_back((int)tab.size());
+                    }
+                    if (comp) l_snappy.push_back((int)tab.size());
+                    tab.push_back(d);
+                }
+            }
+        }
+        // 3. device buffers
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = ensure_buf(ctx, &ctx->pq_stage, &ctx->pq_stage_bytes, stage_total + pq::kInWin + 256);
+        if (rc) return rc;
+        rc = ensure_buf(ctx, &ctx->pq_scratch, &ctx->pq_scratch_bytes, scratch_total + 256);
+        if (rc) return rc;
+        const size_t tab_bytes = align_up(tab.size() * sizeof(pq::PageDev), 256);
+        const size_t ls_bytes = align_up(l_snappy.size() * 4 + 4, 256), ld_bytes = align_up(l_decode.size() * 4 + 4, 256);
+        rc = ensure_buf(ctx, &ctx->pq_tab, &ctx->pq_tab_bytes, tab_bytes + ls_bytes + ld_bytes + 256);
+        if (rc) return rc;
+        char* tb = (char*)ctx->pq_tab;
+        pq::PageDev* d_tab = (pq::PageDev*)tb;
+        int* d_ls = (int*)(tb + tab_bytes); int* d_ld = (int*)(tb + tab_bytes + ls_bytes);
+        int* d_err = (int*)(tb + tab_bytes + ls_bytes + ld_bytes);
+        hipStream_t st = ctx->stream;
+        for (const Span& s : merged)
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->pq_stage + s.stage_off, s.f->bytes + s.start, (size_t)(s.end - s.start), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync((char*)ctx->pq_stage + stage_total, 0, pq::kInWin + 256, st));
+        if (!tab.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(pq::PageDev), hipMemcpyHostToDevice, st));
+        if (!l_snappy.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ls, l_snappy.data(), l_snappy.size() * 4, hipMemcpyHostToDevice, st));
+        if (!l_decode.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ld, l_decode.data(), l_decode.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 8, st));
+        if (!l_snappy.empty())
+            LAUNCH(ctx, K_PQ_SNAPPY, pq::k_pq_snappy, dim3((unsigned)l_snappy.size()), dim3(64), 0, (const unsigned char*)ctx->pq_stage,
+                   (unsigned char*)ctx->pq_scratch, (const pq::PageDev*)d_tab, (const int*)d_ls, d_err);
+        if (!l_decode.empty())
+            LAUNCH(ctx, K_PQ_DECODE, pq::k_pq_decode, dim3((unsigned)l_decode.size()), dim3(256), 0, (const unsigned char*)ctx->pq_stage,
+                   (const unsigned char*)ctx->pq_scratch, (const pq::PageDev*)d_tab, (const int*)d_ld, d_err);
+        int h_err[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h_err, d_err, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        prof_resolve(ctx);
+        if (h_err[0]) {
+            static const char* const what[] = {"", "corrupt Snappy stream", "null values are not supported", "corrupt definition levels",
+                                               "corrupt RLE / bit-packed runs", "dictionary index out of range", "page shorter than its values"};
+            const int c = h_err[0];
+            return fail(ctx, MCR_EINVAL, "parquet: %s (page %d of the request)", (c > 0 && c < 7) ? what[c] : "decode error", h_err[1]);
+        }
+    } catch (const std::exception& e) {
+        return fail(ctx, MCR_ENOMEM, "parquet: host allocation failed: %s", e.what());
+    }
+    return MCR_OK;
+}
+
+int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t M, const int64_t* order, double* dst_dev)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (P < 0 || M < 0 || P > kMaxGridY) return fail(ctx, MCR_EINVAL, "bad shape");
+    if (P == 0 || M == 0) return MCR_OK;
+    if (!src_dev || !dst_dev || !order) return fail(ctx, MCR_EINVAL, "NULL argument");
+    if (src_dev == dst_dev) return fail(ctx, MCR_EINVAL, "gather cannot run in place");
+    for (i64 k = 0; k < M; ++k) if (order[k] < 0 || order[k] >= M) return fail(ctx, MCR_EINVAL, "order[%lld] out of range", (long long)k);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_buf(ctx, &ctx->pq_tab, &ctx->pq_tab_bytes, (size_t)M * 8);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pq_tab, order, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, K_GATHER, mcr::pq::k_gather_rows, dim3((unsigned)((M + 255) / 256), (unsigned)P), dim3(256), 0, src_dev,
+           (const i64*)ctx->pq_tab, (i64)M, dst_dev);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     prof_resolve(ctx);
     return MCR_OK;

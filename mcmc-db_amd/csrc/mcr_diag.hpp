@@ -129,7 +129,6 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
     __shared__ double tot[64];
     __shared__ double wred[NW * 64];
-    __shared__ double red[3 * NW];
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;

@@ -1,0 +1,545 @@
+// mcr_parquet.hpp -- Parquet draws file -> device tensor.
+//
+// The reference reads its draws with pyarrow (`pq.read_table` / `pq.ParquetFile`, src/mcmc_ref/store.py:79-95,
+// src/mcmc_ref/convert.py:61-65) and spends >90 % of an end-to-end `stats` call there once the statistics run on
+// the GPU.  This file is the replacement for that step, written against the published Apache Parquet format
+// (parquet.thrift; Thrift compact protocol; Snappy format description; RLE / bit-packing hybrid), not against
+// pyarrow's sources:
+//
+//   host  : footer + page headers (Thrift compact protocol) -> a flat page table.  Bytes are never decoded on the host.
+//   device: k_pq_snappy  one wavefront per compressed page: raw Snappy -> scratch
+//           k_pq_decode  one workgroup per data page: definition levels checked (nulls are rejected), PLAIN or
+//                        RLE_DICTIONARY / PLAIN_DICTIONARY values -> out[row] as f64 or i64
+//
+// Supported (everything the packaged corpus and pyarrow's default writer produce for flat numeric tables):
+// flat schemas, REQUIRED / OPTIONAL columns without nulls, DOUBLE / FLOAT / INT32 / INT64, UNCOMPRESSED / SNAPPY,
+// data pages v1 and v2, dictionary fallback to PLAIN inside a column chunk, any number of row groups and pages.
+// Everything else fails the call with a message naming the feature -- never a partial answer.
+#pragma once
+#include "mcr_device.hpp"
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mcr {
+namespace pq {
+
+// ---- format constants (parquet.thrift) ---------------------------------------------------------
+enum : int { T_BOOLEAN = 0, T_INT32 = 1, T_INT64 = 2, T_INT96 = 3, T_FLOAT = 4, T_DOUBLE = 5, T_BYTE_ARRAY = 6, T_FLBA = 7 };
+enum : int { ENC_PLAIN = 0, ENC_PLAIN_DICT = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICT = 8 };
+enum : int { CODEC_NONE = 0, CODEC_SNAPPY = 1 };
+enum : int { PAGE_DATA = 0, PAGE_INDEX = 1, PAGE_DICT = 2, PAGE_DATA_V2 = 3 };
+
+// device-side error codes (first error wins; reported with the page index)
+enum : int { PQE_OK = 0, PQE_SNAPPY = 1, PQE_NULLS = 2, PQE_LEVELS = 3, PQE_RUNS = 4, PQE_DICT_INDEX = 5, PQE_SHORT = 6 };
+
+// One page as the kernels see it.  Offsets are bytes into the device staging buffer (`stage`, the uploaded column
+// chunks) or the decompression scratch.
+struct PageDev {
+    u64 src_off;        // payload in stage (for v2: start of the level bytes)
+    u64 dst_off;        // decompressed bytes in scratch (only when compressed)
+    u32 comp_size;      // bytes to decompress (v2: without the levels)
+    u32 uncomp_size;    // size after decompression (v2: without the levels)
+    u32 num_values;
+    u32 lvl_bytes;      // v2: rep + def level bytes in front of the values (never compressed)
+    u32 def_bytes;      // v2: def level bytes (the last `def_bytes` of lvl_bytes)
+    int dict_page;      // data page: index of its dictionary page in the table, -1 = none
+    u32 dict_count;     // data page: entries of that dictionary
+    unsigned char kind, encoding, compressed, phys_type, max_def, out_kind, pad0, pad1;
+    u64 out_off;        // data page: first output element
+    void* out;          // data page: column output (8-byte elements)
+};
+
+// ---- Thrift compact protocol reader (host) -----------------------------------------------------
+struct Thrift {
+    const unsigned char* p; const unsigned char* end; bool ok = true;
+    Thrift(const void* b, size_t n) : p((const unsigned char*)b), end((const unsigned char*)b + n) {}
+    unsigned char byte() { if (p >= end) { ok = false; return 0; } return *p++; }
+    u64 varint() { u64 v = 0; for (int s = 0; s < 64; s += 7) { const unsigned char b = byte(); v |= (u64)(b & 0x7F) << s; if (!(b & 0x80)) return v; } ok = false; return v; }
+    i64 zigzag() { const u64 v = varint(); return (i64)(v >> 1) ^ -(i64)(v & 1); }
+    bool binary(const unsigned char** s, size_t* n) { const u64 l = varint(); if (!ok || l > (u64)(end - p)) { ok = false; return false; } *s = p; *n = (size_t)l; p += l; return true; }
+    // field header: returns type (0 = stop), updates *id
+    int field(int* id) {
+        const unsigned char b = byte();
+        if (!ok || b == 0) return 0;
+        const int delta = b >> 4, type = b & 15;
+        if (delta) *id += delta; else *id = (int)zigzag();
+        return type;
+    }
+    void list_header(int* etype, u64* n) { const unsigned char b = byte(); *etype = b & 15; *n = b >> 4; if (*n == 15) *n = varint(); }
+    void skip(int type, int depth = 0) {
+        if (!ok || depth > 32) { ok = false; return; }
+        switch (type) {
+            case 1: case 2: break;                       // bool carried in the field header
+            case 3: byte(); break;
+            case 4: case 5: case 6: varint(); break;
+            case 7: if (end - p < 8) ok = false; else p += 8; break;
+            case 8: { const unsigned char* s; size_t n; binary(&s, &n); break; }
+            case 9: case 10: { int et; u64 n; list_header(&et, &n); for (u64 i = 0; i < n && ok; ++i) { if (et == 1 || et == 2) byte(); else skip(et, depth + 1); } break; }
+            case 11: { const u64 n = varint(); if (n) { const unsigned char kv = byte(); for (u64 i = 0; i < n && ok; ++i) { skip(kv >> 4, depth + 1); skip(kv & 15, depth + 1); } } break; }
+            case 12: { int id = 0; for (;;) { const int t = field(&id); if (!t || !ok) break; skip(t, depth + 1); } break; }
+            default: ok = false;
+        }
+    }
+};
+
+struct Column { std::string name; int type = -1; int max_def = 0; bool leaf = true; };
+
+struct Page {              // host view of a page
+    int col; int kind; int encoding; int codec;
+    u64 payload_off;       // file offset of the bytes after the page header
+    u32 comp_size, uncomp_size, num_values;
+    u32 rep_bytes = 0, def_bytes = 0; bool v2_compressed = true;
+    u64 row_off = 0;       // data pages: first row of the page within the column
+    int dict = -1;         // data pages: index (into `pages`) of the chunk's dictionary page
+    u32 dict_count = 0;
+};
+
+struct Chunk { int col; u64 start, end; int first_page, n_pages; };
+
+struct File {
+    const unsigned char* bytes = nullptr; size_t len = 0;
+    i64 num_rows = 0;
+    std::vector<Column> cols;
+    std::vector<Page> pages;
+    std::vector<Chunk> chunks;          // per (row group, column), file order
+    std::string created_by;
+    std::string error;
+};
+
+inline bool fail(File& f, const std::string& m) { f.error = m; return false; }
+
+inline bool parse_schema(Thrift& t, File& f)
+{
+    int et; u64 n; t.list_header(&et, &n);
+    if (!t.ok || et != 12 || n < 1) return fail(f, "bad schema list");
+    for (u64 i = 0; i < n; ++i) {
+        int id = 0, type = -1, rep = 0, nchild = -1; std::string name;
+        for (;;) {
+            const int ft = t.field(&id);
+            if (!ft || !t.ok) break;
+            if (id == 1 && ft == 5) type = (int)t.zigzag();
+            else if (id == 3 && ft == 5) rep = (int)t.zigzag();
+            else if (id == 4 && ft == 8) { const unsigned char* s; size_t l; if (t.binary(&s, &l)) name.assign((const char*)s, l); }
+            else if (id == 5 && ft == 5) nchild = (int)t.zigzag();
+            else t.skip(ft);
+        }
+        if (!t.ok) return fail(f, "truncated schema element");
+        if (i == 0) { if ((u64)nchild != n - 1) return fail(f, "nested schemas are not supported (only flat tables)"); continue; }
+        if (nchild > 0) return fail(f, "nested schemas are not supported (only flat tables)");
+        if (rep == 2) return fail(f, "REPEATED column '" + name + "' is not supported");
+        Column c; c.name = name; c.type = type; c.max_def = rep == 1 ? 1 : 0;
+        f.cols.push_back(c);
+    }
+    return true;
+}
+
+struct ChunkMeta { int type = -1, codec = 0; i64 num_values = 0, data_off = -1, dict_off = -1, comp_total = 0; };
+
+inline bool parse_column_meta(Thrift& t, ChunkMeta& m)
+{
+    int id = 0;
+    for (;;) {
+        const int ft = t.field(&id);
+        if (!ft || !t.ok) break;
+        if (id == 1 && ft == 5) m.type = (int)t.zigzag();
+        else if (id == 4 && ft == 5) m.codec = (int)t.zigzag();
+        else if (id == 5 && ft == 6) m.num_values = t.zigzag();
+        else if (id == 7 && ft == 6) m.comp_total = t.zigzag();
+        else if (id == 9 && ft == 6) m.data_off = t.zigzag();
+        else if (id == 11 && ft == 6) m.dict_off = t.zigzag();
+        else t.skip(ft);
+    }
+    return t.ok;
+}
+
+// Page header at `off`; fills pg (payload_off = first byte after the header).
+inline bool parse_page_header(File& f, u64 off, Page& pg)
+{
+    if (off >= f.len) return fail(f, "page header beyond the end of the file");
+    Thrift t(f.bytes + off, f.len - off);
+    int id = 0; i64 type = -1, usz = -1, csz = -1;
+    pg.num_values = 0; pg.encoding = -1;
+    for (;;) {
+        const int ft = t.field(&id);
+        if (!ft || !t.ok) break;
+        if (id == 1 && ft == 5) type = t.zigzag();
+        else if (id == 2 && ft == 5) usz = t.zigzag();
+        else if (id == 3 && ft == 5) csz = t.zigzag();
+        else if ((id == 5 || id == 7 || id == 8) && ft == 12) {
+            int sid = 0;
+            for (;;) {
+                const int st = t.field(&sid);
+                if (!st || !t.ok) break;
+                if (id == 5 || id == 7) {                 // DataPageHeader / DictionaryPageHeader
+                    if (sid == 1 && st == 5) pg.num_values = (u32)t.zigzag();
+                    else if (sid == 2 && st == 5) pg.encoding = (int)t.zigzag();
+                    else t.skip(st);
+                } else {                                  // DataPageHeaderV2
+                    if (sid == 1 && st == 5) pg.num_values = (u32)t.zigzag();
+                    else if (sid == 4 && st == 5) pg.encoding = (int)t.zigzag();
+                    else if (sid == 5 && st == 5) pg.def_bytes = (u32)t.zigzag();
+                    else if (sid == 6 && st == 5) pg.rep_bytes = (u32)t.zigzag();
+                    else if (sid == 7 && (st == 1 || st == 2)) pg.v2_compressed = (st == 1);
+                    else t.skip(st);
+                }
+            }
+        } else t.skip(ft);
+    }
+    if (!t.ok || type < 0 || usz < 0 || csz < 0) return fail(f, "truncated or malformed page header");
+    pg.kind = (int)type; pg.uncomp_size = (u32)usz; pg.comp_size = (u32)csz;
+    pg.payload_off = off + (u64)(t.p - (f.bytes + off));
+    if (pg.payload_off + pg.comp_size > f.len) return fail(f, "page payload beyond the end of the file");
+    return true;
+}
+
+// Parses footer, schema, row groups and walks the page headers of every column chunk.
+inline bool open(File& f, const void* bytes, size_t len)
+{
+    f.bytes = (const unsigned char*)bytes; f.len = len;
+    if (len < 12 || memcmp(f.bytes, "PAR1", 4) != 0 || memcmp(f.bytes + len - 4, "PAR1", 4) != 0)
+        return fail(f, len >= 4 && memcmp(f.bytes + len - 4, "PARE", 4) == 0 ? "encrypted Parquet files are not supported"
+                                                                            : "not a Parquet file (magic bytes)");
+    u32 flen; memcpy(&flen, f.bytes + len - 8, 4);
+    if ((u64)flen + 12 > len) return fail(f, "footer length out of range");
+    Thrift t(f.bytes + len - 8 - flen, flen);
+    int id = 0; bool have_schema = false;
+    struct RG { std::vector<ChunkMeta> cm; i64 rows = 0; };
+    std::vector<RG> rgs;
+    for (;;) {
+        const int ft = t.field(&id);
+        if (!ft || !t.ok) break;
+        if (id == 2 && ft == 9) { if (!parse_schema(t, f)) return false; have_schema = true; }
+        else if (id == 3 && ft == 6) f.num_rows = t.zigzag();
+        else if (id == 4 && ft == 9) {
+            int et; u64 n; t.list_header(&et, &n);
+            for (u64 r = 0; r < n && t.ok; ++r) {
+                RG rg; int rid = 0;
+                for (;;) {
+                    const int rt = t.field(&rid);
+                    if (!rt || !t.ok) break;
+                    if (rid == 1 && rt == 9) {
+                        int cet; u64 cn; t.list_header(&cet, &cn);
+                        for (u64 c = 0; c < cn && t.ok; ++c) {
+                            ChunkMeta m; int cid = 0; bool external = false;
+                            for (;;) {
+                                const int ct = t.field(&cid);
+                                if (!ct || !t.ok) break;
+                                if (cid == 1 && ct == 8) { const unsigned char* s; size_t l; t.binary(&s, &l); external = l > 0; }
+                                else if (cid == 3 && ct == 12) { if (!parse_column_meta(t, m)) return fail(f, "truncated column metadata"); }
+                                else t.skip(ct);
+                            }
+                            if (external) return fail(f, "column chunks in external files are not supported");
+                            rg.cm.push_back(m);
+                        }
+                    } else if (rid == 3 && rt == 6) rg.rows = t.zigzag();
+                    else t.skip(rt);
+                }
+                rgs.push_back(rg);
+            }
+        } else if (id == 6 && ft == 8) { const unsigned char* s; size_t l; if (t.binary(&s, &l)) f.created_by.assign((const char*)s, l); }
+        else t.skip(ft);
+    }
+    if (!t.ok || !have_schema) return fail(f, "truncated or malformed footer");
+    if (f.num_rows < 0 || f.num_rows >= (i64)0x7FFFFFFF) return fail(f, "row count out of range");
+    std::vector<u64> rows_done(f.cols.size(), 0);
+    for (const RG& rg : rgs) {
+        if (rg.cm.size() != f.cols.size()) return fail(f, "row group column count differs from the schema");
+        for (size_t c = 0; c < rg.cm.size(); ++c) {
+            const ChunkMeta& m = rg.cm[c];
+            if (m.type != f.cols[c].type) return fail(f, "column chunk type differs from the schema");
+            if (m.data_off < 0 || m.comp_total < 0) return fail(f, "column chunk without offsets");
+            u64 off = (m.dict_off > 0 && m.dict_off < m.data_off) ? (u64)m.dict_off : (u64)m.data_off;
+            const u64 end = off + (u64)m.comp_total;
+            if (end > len) return fail(f, "column chunk beyond the end of the file");
+            Chunk ch; ch.col = (int)c; ch.start = off; ch.end = end; ch.first_page = (int)f.pages.size(); ch.n_pages = 0;
+            int dict = -1; u32 dict_count = 0; i64 seen = 0;
+            while (off < end && seen < m.num_values) {
+                Page pg; pg.col = (int)c; pg.codec = m.codec;
+                if (!parse_page_header(f, off, pg)) return false;
+                off = pg.payload_off + pg.comp_size;
+                if (pg.kind == PAGE_INDEX) continue;
+                if (pg.kind == PAGE_DICT) { dict = (int)f.pages.size(); dict_count = pg.num_values; }
+                else if (pg.kind == PAGE_DATA || pg.kind == PAGE_DATA_V2) {
+                    pg.row_off = rows_done[c] + (u64)seen; pg.dict = dict; pg.dict_count = dict_count;
+                    seen += pg.num_values;
+                    if (pg.kind == PAGE_DATA_V2 && (u64)pg.rep_bytes + pg.def_bytes > pg.comp_size) return fail(f, "v2 level bytes exceed the page");
+                } else return fail(f, "unknown page type " + std::to_string(pg.kind));
+                f.pages.push_back(pg); ++ch.n_pages;
+            }
+            if (seen != m.num_values) return fail(f, "pages of column '" + f.cols[c].name + "' do not add up to its value count");
+            rows_done[c] += (u64)seen;
+            f.chunks.push_back(ch);
+        }
+    }
+    for (size_t c = 0; c < f.cols.size(); ++c)
+        if ((i64)rows_done[c] != f.num_rows) return fail(f, "column '" + f.cols[c].name + "' does not have num_rows values");
+    return true;
+}
+
+// ---- device helpers ----------------------------------------------------------------------------
+// Loads from arbitrarily aligned addresses as aligned dwords + v_alignbit (no reliance on the memory system's
+// unaligned mode).  May touch up to 3 bytes in front of and 7 bytes behind the value: stage and scratch buffers are
+// padded accordingly.
+__device__ __forceinline__ u64 ld64u(const unsigned char* p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const u32* w = (const u32*)(a & ~(uintptr_t)3);
+    const u32 sh = (u32)(a & 3) * 8;
+    const u32 w0 = w[0], w1 = w[1], w2 = w[2];
+    return (u64)__funnelshift_r(w0, w1, sh) | ((u64)__funnelshift_r(w1, w2, sh) << 32);
+}
+__device__ __forceinline__ u32 ld32u(const unsigned char* p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const u32* w = (const u32*)(a & ~(uintptr_t)3);
+    const u32 sh = (u32)(a & 3) * 8;
+    return __funnelshift_r(w[0], w[1], sh);
+}
+
+__device__ __forceinline__ void pq_error(int* err, int code, int page)
+{
+    if (atomicCAS(err, 0, code) == 0) err[1] = page;
+}
+
+// ---- Snappy (raw format) -----------------------------------------------------------------------
+// One wavefront per page; the element stream is parsed by all lanes in lock step from an LDS window of the input,
+// and the lanes share each literal / copy.  The last kRing output bytes are mirrored in LDS so that back references
+// (always within 64 KB in practice, almost always within a few KB) never wait on global memory; farther ones read
+// the output back behind a workgroup fence.
+constexpr int kRing = 32768, kInWin = 4096;
+
+__global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restrict__ stage, unsigned char* scratch,
+                                                  const PageDev* __restrict__ pages, const int* __restrict__ list,
+                                                  int* err)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ring[kRing];
+    __shared__ __attribute__((aligned(16))) unsigned char inb[kInWin];
+    const int pi = list[blockIdx.x];
+    const PageDev pg = pages[pi];
+    const int lane = threadIdx.x;
+    const unsigned char* src = stage + pg.src_off + pg.lvl_bytes;
+    unsigned char* dst = scratch + pg.dst_off;
+    const u32 n_in = pg.comp_size, n_out = pg.uncomp_size;
+    // preamble: uncompressed length
+    u32 ip = 0, ulen = 0;
+    for (int s = 0; s < 35 && ip < n_in; s += 7) { const u32 b = src[ip++]; ulen |= (b & 0x7F) << s; if (!(b & 0x80)) break; }
+    if (ulen != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); return; }
+    i64 win = -(i64)kInWin * 2;          // input offset of inb[0]; the window is [win, win + kInWin)
+    const uintptr_t src_a = (uintptr_t)src;
+    u32 op = 0;
+    bool bad = false;
+    while (ip < n_in && !bad) {
+        if ((i64)ip < win || (i64)ip + 5 > win + kInWin) {             // refill: 16-byte aligned global loads
+            win = (i64)ip - (i64)((src_a + ip) & 15);
+            __syncthreads();
+            for (int o = lane * 16; o < kInWin; o += 64 * 16)
+                *(uint4*)(inb + o) = *(const uint4*)(src + win + o);     // reads past n_in stay inside the padded stage
+            __syncthreads();
+        }
+        const unsigned char* q = inb + ((i64)ip - win);
+        const u32 tag = q[0], b1 = q[1], b2 = q[2], b3 = q[3], b4 = q[4];
+        if ((tag & 3) == 0) {                                            // literal
+            u32 len = tag >> 2, hdr = 1;
+            if (len >= 60) {
+                const u32 nb = len - 59; hdr += nb;
+                const u32 v = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
+                len = nb == 4 ? v : (v & ((1u << (8 * nb)) - 1));
+            }
+            len += 1; ip += hdr;
+            if (ip > n_in || len > n_in - ip || len > n_out - op) { bad = true; break; }
+            if (len <= 64 && (i64)ip + len <= win + kInWin) {            // short literal inside the window
+                if (lane < (int)len) {
+                    const unsigned char b = inb[(i64)ip - win + lane];
+                    ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b;
+                }
+            } else {                                                     // long literal: 16 bytes per lane and step
+                const unsigned char* s = src + ip;
+                const u32 h = min(len, (16u - (op & 15)) & 15);
+                if (lane < (int)h) { const unsigned char b = s[lane]; ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b; }
+                const unsigned char* s2 = s + h;
+                const u32 nv = (len - h) >> 4, o2 = op + h;
+                const uintptr_t a2 = (uintptr_t)s2;
+                const u32* w = (const u32*)(a2 & ~(uintptr_t)3);
+                const u32 sh = (u32)(a2 & 3) * 8;
+                for (u32 v = lane; v < nv; v += 64) {
+                    const u32 w0 = w[4 * v], w1 = w[4 * v + 1], w2 = w[4 * v + 2], w3 = w[4 * v + 3], w4 = w[4 * v + 4];
+                    uint4 x;
+                    x.x = __funnelshift_r(w0, w1, sh); x.y = __funnelshift_r(w1, w2, sh);
+                    x.z = __funnelshift_r(w2, w3, sh); x.w = __funnelshift_r(w3, w4, sh);
+                    *(uint4*)(dst + o2 + 16 * v) = x;
+                    *(uint4*)(ring + ((o2 + 16 * v) & (kRing - 1))) = x;
+                }
+                const u32 tl = (len - h) & 15, o3 = o2 + 16 * nv;
+                if (lane < (int)tl) { const unsigned char b = s2[16 * nv + lane]; ring[(o3 + lane) & (kRing - 1)] = b; dst[o3 + lane] = b; }
+            }
+            ip += len; op += len;
+        } else {                                                         // copy
+            u32 len, off;
+            if ((tag & 3) == 1) { len = 4 + ((tag >> 2) & 7); off = ((tag >> 5) << 8) | b1; ip += 2; }
+            else if ((tag & 3) == 2) { len = (tag >> 2) + 1; off = b1 | (b2 << 8); ip += 3; }
+            else { len = (tag >> 2) + 1; off = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); ip += 5; }
+            if (off == 0 || off > op || len > n_out - op || ip > n_in) { bad = true; break; }
+            unsigned char b = 0;
+            const u32 k = (off >= len) ? (u32)lane : (u32)lane % off;    // overlapping copies repeat the last `off` bytes
+            if (off <= kRing) {
+                if (lane < (int)len) b = ring[(op - off + k) & (kRing - 1)];
+            } else {
+                __threadfence_block();
+                __syncthreads();
+                if (lane < (int)len) b = ((volatile unsigned char*)dst)[op - off + k];
+            }
+            __syncthreads();
+            if (lane < (int)len) { ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b; }
+            op += len;
+        }
+        __syncthreads();
+    }
+    if (bad || op != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); }
+}
+
+// ---- page decode -------------------------------------------------------------------------------
+__device__ __forceinline__ u32 pq_varint(const unsigned char*& p, const unsigned char* end)
+{
+    u32 v = 0;
+    for (int s = 0; s < 35 && p < end; s += 7) { const u32 b = *p++; v |= (b & 0x7F) << s; if (!(b & 0x80)) break; }
+    return v;
+}
+
+template <int OUT_I64>
+__device__ __forceinline__ void pq_store(void* out, u64 i, u64 bits, int phys)
+{
+    // bits: the raw little-endian value (8 bytes for INT64 / DOUBLE, low 4 for INT32 / FLOAT)
+    if (OUT_I64) {
+        ((i64*)out)[i] = phys == T_INT64 ? (i64)bits : (i64)(int)(u32)bits;
+    } else {
+        double v;
+        if (phys == T_DOUBLE) v = __longlong_as_double((i64)bits);
+        else if (phys == T_FLOAT) v = (double)__uint_as_float((u32)bits);
+        else if (phys == T_INT64) v = (double)(i64)bits;
+        else v = (double)(int)(u32)bits;
+        ((double*)out)[i] = v;
+    }
+}
+
+// One workgroup per data page.  All threads walk the run headers in lock step (uniform loads); the values of a run are
+// spread over the threads.
+__global__ __launch_bounds__(256) void k_pq_decode(const unsigned char* __restrict__ stage,
+                                                   const unsigned char* __restrict__ scratch,
+                                                   const PageDev* __restrict__ pages, const int* __restrict__ list,
+                                                   int* err)
+{
+    const int pi = list[blockIdx.x];
+    const PageDev pg = pages[pi];
+    const int tid = threadIdx.x;
+    const unsigned char* lvl = nullptr; u32 lvl_len = 0;
+    const unsigned char* val; const unsigned char* vend;
+    if (pg.kind == PAGE_DATA_V2) {
+        lvl = stage + pg.src_off + (pg.lvl_bytes - pg.def_bytes); lvl_len = pg.def_bytes;
+        val = pg.compressed ? scratch + pg.dst_off : stage + pg.src_off + pg.lvl_bytes;
+        vend = val + pg.uncomp_size;
+    } else {
+        val = pg.compressed ? scratch + pg.dst_off : stage + pg.src_off;
+        vend = val + pg.uncomp_size;
+        if (pg.max_def) {
+            if (vend - val < 4) { if (tid == 0) pq_error(err, PQE_SHORT, pi); return; }
+            lvl_len = ld32u(val); lvl = val + 4;
+            if (lvl_len > (u32)(vend - lvl)) { if (tid == 0) pq_error(err, PQE_LEVELS, pi); return; }
+            val = lvl + lvl_len;
+        }
+    }
+    const u32 nv = pg.num_values;
+    // definition levels (bit width 1): every value must be defined
+    if (pg.max_def && nv) {
+        const unsigned char* p = lvl; const unsigned char* pe = lvl + lvl_len;
+        u32 seen = 0; int flag = 0;
+        while (seen < nv && p < pe) {
+            const u32 h = pq_varint(p, pe);
+            if (h & 1) {
+                const u32 groups = h >> 1, cnt = min(groups * 8, nv - seen);
+                if (groups > (u32)(pe - p)) { flag = PQE_LEVELS; break; }
+                for (u32 g = tid; g * 8 < cnt; g += 256) {
+                    const u32 m = (cnt - g * 8 >= 8) ? 0xFFu : ((1u << (cnt - g * 8)) - 1);
+                    if ((p[g] & m) != m) flag = PQE_NULLS;
+                }
+                p += groups; seen += cnt;
+            } else {
+                const u32 cnt = h >> 1;
+                if (p >= pe) { flag = PQE_LEVELS; break; }
+                if (cnt && (*p & 1) == 0) flag = PQE_NULLS;
+                p += 1; seen += min(cnt, nv - seen);
+                if (cnt == 0) { flag = PQE_LEVELS; break; }
+            }
+        }
+        if (!flag && seen < nv) flag = PQE_LEVELS;
+        if (__syncthreads_or(flag)) { if (flag) pq_error(err, flag, pi); return; }
+    }
+    const int phys = pg.phys_type;
+    const u32 es = (phys == T_INT64 || phys == T_DOUBLE) ? 8 : 4;
+    void* out = (char*)pg.out + pg.out_off * 8;
+    if (pg.encoding == ENC_PLAIN) {
+        if ((u64)nv * es > (u64)(vend - val)) { if (tid == 0) pq_error(err, PQE_SHORT, pi); return; }
+        for (u32 i = tid; i < nv; i += 256) {
+            const u64 bits = es == 8 ? ld64u(val + (u64)i * 8) : (u64)ld32u(val + (u64)i * 4);
+            if (pg.out_kind) pq_store<1>(out, i, bits, phys); else pq_store<0>(out, i, bits, phys);
+        }
+        return;
+    }
+    // dictionary indices: 1 byte bit width, then RLE / bit-packed hybrid runs
+    const PageDev dp = pages[pg.dict_page];
+    const unsigned char* dict = dp.compressed ? scratch + dp.dst_off : stage + dp.src_off;
+    const u32 dn = pg.dict_count;
+    if (nv == 0) return;
+    if (val >= vend) { if (tid == 0) pq_error(err, PQE_SHORT, pi); return; }
+    const u32 bw = *val++;
+    if (bw > 32) { if (tid == 0) pq_error(err, PQE_RUNS, pi); return; }
+    const u64 mask = bw == 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1);
+    u32 done = 0; int flag = 0;
+    while (done < nv) {
+        if (val >= vend) { flag = PQE_RUNS; break; }
+        const u32 h = pq_varint(val, vend);
+        if (h & 1) {
+            const u32 groups = h >> 1;
+            const u64 bytes = (u64)groups * bw;
+            const u32 cnt = (u32)min((u64)groups * 8, (u64)(nv - done));
+            if (groups == 0 || ((u64)cnt * bw + 7) / 8 > (u64)(vend - val)) { flag = PQE_RUNS; break; }   // the last run may be cut short
+            for (u32 i = tid; i < cnt; i += 256) {
+                const u64 bit = (u64)i * bw;
+                const u32 idx = (u32)((ld64u(val + (bit >> 3)) >> (bit & 7)) & mask);
+                if (idx >= dn) { flag = PQE_DICT_INDEX; continue; }
+                const u64 bits = es == 8 ? ld64u(dict + (u64)idx * 8) : (u64)ld32u(dict + (u64)idx * 4);
+                if (pg.out_kind) pq_store<1>(out, done + i, bits, phys); else pq_store<0>(out, done + i, bits, phys);
+            }
+            val += min(bytes, (u64)(vend - val)); done += cnt;
+        } else {
+            const u32 cnt0 = h >> 1, nb = (bw + 7) / 8;
+            if (cnt0 == 0 || nb > (u32)(vend - val)) { flag = PQE_RUNS; break; }
+            u32 idx = 0;
+            for (u32 b = 0; b < nb; ++b) idx |= (u32)val[b] << (8 * b);
+            val += nb;
+            const u32 cnt = min(cnt0, nv - done);
+            if (idx >= dn) { flag = PQE_DICT_INDEX; break; }
+            const u64 bits = es == 8 ? ld64u(dict + (u64)idx * 8) : (u64)ld32u(dict + (u64)idx * 4);
+            for (u32 i = tid; i < cnt; i += 256) {
+                if (pg.out_kind) pq_store<1>(out, done + i, bits, phys); else pq_store<0>(out, done + i, bits, phys);
+            }
+            done += cnt;
+        }
+    }
+    if (__syncthreads_or(flag)) { if (flag) pq_error(err, flag, pi); }
+}
+
+// dst[p][k] = src[p][order[k]]  (rows of a long table that are not in (chain, draw) order; `_chains_from_table`,
+// src/mcmc_ref/convert.py:150-161)
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ src, const i64* __restrict__ order,
+                                                     i64 M, double* __restrict__ dst)
+{
+    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 p = blockIdx.y;
+    if (k < M) dst[p * M + k] = src[p * M + order[k]];
+}
+
+}  // namespace pq
+}  // namespace mcr

@@ -51,6 +51,13 @@ class ModelDesc(C.Structure):
                 ("stride_c", C.c_int64), ("stride_n", C.c_int64), ("stride_p", C.c_int64)]
 
 
+class ParquetRequest(C.Structure):
+    _fields_ = [("file", C.c_void_p), ("column", C.c_int), ("out_kind", C.c_int), ("out_dev", C.c_void_p)]
+
+
+MCR_PQ_F64, MCR_PQ_I64 = 0, 1
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -87,6 +94,16 @@ SYMBOLS = {
     "mcr_profile_reset": (C.c_int, [C.c_void_p]),
     "mcr_profile_get": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
     "mcr_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _I64, _I64, C.c_uint64]),
+    "mcr_parquet_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mcr_parquet_close": (None, [C.c_void_p]),
+    "mcr_parquet_num_rows": (C.c_int64, [C.c_void_p]),
+    "mcr_parquet_num_columns": (C.c_int, [C.c_void_p]),
+    "mcr_parquet_column_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "mcr_parquet_column_type": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcr_parquet_num_pages": (C.c_int, [C.c_void_p]),
+    "mcr_parquet_page_info": (C.c_int, [C.c_void_p, C.c_int, _ip]),
+    "mcr_parquet_decode": (C.c_int, [C.c_void_p, C.POINTER(ParquetRequest), C.c_int]),
+    "mcr_gather_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, _I64, _I64, _ip, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,208 @@
+"""Native Parquet ingest: draws file -> device tensor, no pyarrow on the path.
+
+Counterpart of the reference's `pq.read_table` / `pq.ParquetFile(...).iter_batches` + `to_numpy`
+(src/mcmc_ref/store.py:79-95, src/mcmc_ref/convert.py:61-65, src/mcmc_ref/backends_numpy.py:35) for the
+on-disk layout `draws/<model>.draws.parquet` (long table: `chain`, `draw`, one DOUBLE column per parameter).
+Footer and page headers are parsed on the host by the C library, the page payloads are decompressed and
+decoded by HIP kernels straight into HBM; the statistics then run on that tensor without a host round trip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import mmap
+import os
+from pathlib import Path
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import MCR_F64, MCR_PQ_F64, MCR_PQ_I64, DeviceBuffer, DeviceTensor, McrError, ParquetRequest
+
+PHYSICAL_TYPES = {0: "BOOLEAN", 1: "INT32", 2: "INT64", 3: "INT96", 4: "FLOAT", 5: "DOUBLE", 6: "BYTE_ARRAY",
+                  7: "FIXED_LEN_BYTE_ARRAY"}
+NUMERIC = (1, 2, 4, 5)
+
+
+class ParquetFile:
+    """Parsed metadata of one Parquet file image (bytes, mmap or path).  Parsing needs no GPU."""
+
+    def __init__(self, source, context: "_ffi.Context | None" = None):
+        self.lib = _ffi.load_library()
+        self.ctx = context
+        self._mm = None
+        if isinstance(source, (str, os.PathLike)):
+            self.path = Path(source)
+            with open(self.path, "rb") as fh:
+                size = os.fstat(fh.fileno()).st_size
+                if size == 0:
+                    raise McrError(_ffi.MCR_EINVAL, f"parquet: {self.path} is empty")
+                self._mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            self._image = np.frombuffer(self._mm, dtype=np.uint8)
+        else:
+            self.path = None
+            self._image = np.frombuffer(source, dtype=np.uint8)
+        self.handle = C.c_void_p()
+        rc = self.lib.mcr_parquet_open(context.handle if context else None, self._image.ctypes.data_as(C.c_void_p),
+                                       self._image.size, C.byref(self.handle))
+        if rc != _ffi.MCR_OK:
+            msg = (self.lib.mcr_last_error(context.handle if context else None) or b"").decode()
+            self.handle = None
+            raise McrError(rc, msg)
+        self.num_rows = int(self.lib.mcr_parquet_num_rows(self.handle))
+        n = self.lib.mcr_parquet_num_columns(self.handle)
+        self.column_names = [self.lib.mcr_parquet_column_name(self.handle, i).decode() for i in range(n)]
+        self.column_types = [self.lib.mcr_parquet_column_type(self.handle, i) for i in range(n)]
+
+    def pages(self) -> list[dict]:
+        keys = ("column", "kind", "encoding", "codec", "payload_offset", "compressed_size", "uncompressed_size",
+                "num_values", "first_row", "dictionary_page")
+        out, info = [], np.zeros(10, dtype=np.int64)
+        for i in range(self.lib.mcr_parquet_num_pages(self.handle)):
+            self.lib.mcr_parquet_page_info(self.handle, i, info.ctypes.data_as(C.POINTER(C.c_int64)))
+            out.append(dict(zip(keys, (int(v) for v in info))))
+        return out
+
+    def index(self, name: str) -> int:
+        try:
+            return self.column_names.index(name)
+        except ValueError:
+            raise KeyError(f"column {name!r} not in {self.path or 'parquet image'}") from None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mcr_parquet_close(self.handle)
+            self.handle = None
+        self._image = None
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:      # a numpy view is still alive somewhere; the mapping goes with it
+                pass
+            self._mm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode(ctx: "_ffi.Context", requests: Sequence[tuple[ParquetFile, int, int, C.c_void_p]]):
+    """One upload + two launches for all (file, column index, out_kind, device pointer) requests."""
+    arr = (ParquetRequest * max(len(requests), 1))()
+    for i, (f, col, kind, ptr) in enumerate(requests):
+        arr[i].file, arr[i].column, arr[i].out_kind = f.handle, col, kind
+        arr[i].out_dev = ptr if isinstance(ptr, int) else ptr.value
+    ctx._check(ctx.lib.mcr_parquet_decode(ctx.handle, arr, len(requests)))
+
+
+def _layout(chain: np.ndarray, draw: np.ndarray):
+    """(chain ids, order or None, draws per chain) -- the integer bookkeeping of `_chains_from_table`
+    (src/mcmc_ref/convert.py:150-161); same rule as convert.chain_layout."""
+    ids, counts = np.unique(chain, return_counts=True)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    already = chain.size == 0 or (np.all(np.diff(chain) >= 0) and
+                                  all(np.all(np.diff(draw[s:s + n]) >= 0) for s, n in zip(starts, counts)))
+    order = None if already else np.lexsort((draw, chain))
+    return ids, order, counts
+
+
+class DeviceDraws:
+    """Draws of one model in HBM: `tensor` is [P][M] f64 in (chain, draw) order; counts = draws per chain."""
+
+    def __init__(self, tensor: DeviceTensor | None, buf: DeviceBuffer, params: list[str], chain_ids: np.ndarray,
+                 counts: np.ndarray):
+        self.tensor, self.buf, self.params, self.chain_ids, self.counts = tensor, buf, params, chain_ids, counts
+
+    @property
+    def rectangular(self) -> bool:
+        return len(self.counts) > 0 and bool(np.all(self.counts == self.counts[0]))
+
+    def to_host(self) -> np.ndarray:
+        M = int(self.counts.sum())
+        return self.buf.download(np.float64, len(self.params) * M).reshape(len(self.params), M)
+
+    def free(self):
+        self.buf.free()
+
+
+def read_draws_many(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Iterable[str] | None] | None = None
+                    ) -> list[DeviceDraws]:
+    """Decodes many draws files with one batched decode call (all pages of all files in one grid)."""
+    files = [s if isinstance(s, ParquetFile) else ParquetFile(s, ctx) for s in sources]
+    owned = [not isinstance(s, ParquetFile) for s in sources]
+    try:
+        reqs, plan, bufs = [], [], []
+        for k, f in enumerate(files):
+            want = list(params[k]) if params is not None and params[k] is not None else \
+                [n for n, t in zip(f.column_names, f.column_types) if n not in ("chain", "draw") and t in NUMERIC]
+            cols = [f.index(n) for n in want]
+            M = f.num_rows
+            buf = DeviceBuffer(ctx, max(len(cols) * M * 8, 8))
+            ids = DeviceBuffer(ctx, max(2 * M * 8, 8))
+            base, ibase = buf.ptr.value, ids.ptr.value
+            for j, c in enumerate(cols):
+                reqs.append((f, c, MCR_PQ_F64, base + j * M * 8))
+            reqs.append((f, f.index("chain"), MCR_PQ_I64, ibase))
+            reqs.append((f, f.index("draw"), MCR_PQ_I64, ibase + M * 8))
+            plan.append((want, M, buf, ids))
+            bufs += [buf, ids]
+        try:
+            decode(ctx, reqs)
+        except Exception:
+            for b in bufs:
+                b.free()
+            raise
+        out = []
+        for want, M, buf, ids in plan:
+            cd = ids.download(np.int64, 2 * M)
+            ids.free()
+            chain_ids, order, counts = _layout(cd[:M], cd[M:])
+            if order is not None and want and M:
+                dst = DeviceBuffer(ctx, len(want) * M * 8)
+                order = np.ascontiguousarray(order, dtype=np.int64)
+                ctx._check(ctx.lib.mcr_gather_rows_dev(ctx.handle, buf.ptr, len(want), M,
+                                                       order.ctypes.data_as(C.POINTER(C.c_int64)), dst.ptr))
+                buf.free()
+                buf = dst
+            tensor = None
+            if len(counts) and np.all(counts == counts[0]):
+                Cn, N = len(counts), int(counts[0])
+                tensor = DeviceTensor(ctx, buf, (MCR_F64, Cn, N, len(want), N, 1, Cn * N))
+            out.append(DeviceDraws(tensor, buf, want, chain_ids, counts))
+        return out
+    finally:
+        for f, o in zip(files, owned):
+            if o:
+                f.close()
+
+
+def read_draws(ctx: "_ffi.Context", source, params: Iterable[str] | None = None) -> DeviceDraws:
+    return read_draws_many(ctx, [source], [params])[0]
+
+
+def read_columns(ctx: "_ffi.Context", source, columns: Iterable[str] | None = None) -> dict[str, np.ndarray]:
+    """Host arrays of numeric columns decoded on the device (ints as int64, floats as float64)."""
+    f = source if isinstance(source, ParquetFile) else ParquetFile(source, ctx)
+    try:
+        names = list(columns) if columns is not None else [n for n, t in zip(f.column_names, f.column_types) if t in NUMERIC]
+        M = f.num_rows
+        buf = DeviceBuffer(ctx, max(len(names) * M * 8, 8))
+        try:
+            kinds = [MCR_PQ_I64 if f.column_types[f.index(n)] in (1, 2) else MCR_PQ_F64 for n in names]
+            decode(ctx, [(f, f.index(n), k, buf.ptr.value + j * M * 8) for j, (n, k) in enumerate(zip(names, kinds))])
+            raw = buf.download(np.int64, len(names) * M).reshape(len(names), M)
+        finally:
+            buf.free()
+        return {n: (raw[j].copy() if k == MCR_PQ_I64 else raw[j].view(np.float64).copy())
+                for j, (n, k) in enumerate(zip(names, kinds))}
+    finally:
+        if not isinstance(source, ParquetFile):
+            f.close()

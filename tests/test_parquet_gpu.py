@@ -1,0 +1,206 @@
+"""Native Parquet ingest on the GPU: `mcr_parquet_decode` through the C ABI against
+pyarrow's decode of the same file image -- pyarrow IS the reference's reader for this step
+(`pq.read_table`, src/mcmc_ref/store.py:79-95), so equality here is parity with the reference's ingest.
+Bit-exact for every value (doubles compared as bit patterns)."""
+from __future__ import annotations
+
+import io
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from conftest import GOLDEN, load_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mcmc_ref_hip._ffi import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def image(table, **kw) -> bytes:
+    buf = io.BytesIO()
+    pq.write_table(table, buf, **kw)
+    return buf.getvalue()
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int64) if a.dtype == np.float64 else a
+
+
+def check_roundtrip(ctx, img: bytes, columns=None):
+    from mcmc_ref_hip.parquet import read_columns
+    t = pq.read_table(io.BytesIO(img))
+    got = read_columns(ctx, img, columns)
+    names = columns if columns is not None else [f.name for f in t.schema if pa.types.is_integer(f.type) or
+                                                 pa.types.is_floating(f.type)]
+    assert list(got) == list(names)
+    for n in names:
+        col = t[n].to_numpy()
+        exp = col.astype(np.int64) if np.issubdtype(col.dtype, np.integer) else col.astype(np.float64)
+        assert got[n].dtype == exp.dtype, n
+        assert np.array_equal(bits(got[n]), bits(exp)), n
+    return got
+
+
+def mixed_table(n=6000, seed=3):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=n)
+    x[::97] = -0.0
+    x[5] = np.inf; x[6] = -np.inf; x[7] = np.nan; x[8] = 5e-324
+    return pa.table({
+        "chain": np.repeat(np.arange(4), n // 4), "draw": np.tile(np.arange(n // 4), 4),
+        "x": x,
+        "ties": np.round(rng.normal(size=n), 1),                 # ~60 distinct values: small dictionary, 6-bit indices
+        "const": np.full(n, 2.5),                                # one dictionary entry: bit width 0
+        "runs": np.repeat(rng.normal(size=n // 50), 50),         # RLE runs inside the index stream
+        "f32": rng.normal(size=n).astype(np.float32),
+        "i32": rng.integers(-1000, 1000, n).astype(np.int32),
+        "i64": rng.integers(-2**40, 2**40, n),
+        "label": pa.array([str(i % 5) for i in range(n)]),       # not numeric: present, never requested
+    })
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(compression="none"),
+    dict(use_dictionary=False),
+    dict(data_page_version="2.0"),
+    dict(data_page_version="2.0", compression="none"),
+    dict(row_group_size=700),
+    dict(data_page_size=2048, write_batch_size=64),
+    dict(data_page_size=1500, write_batch_size=32, row_group_size=1700, data_page_version="2.0"),
+    dict(use_dictionary=["ties", "runs"], compression={"x": "none", "ties": "snappy"}),
+])
+def test_roundtrip_writer_options(ctx, kw):
+    check_roundtrip(ctx, image(mixed_table(), **kw))
+
+
+def test_required_columns_and_subsets(ctx):
+    n = 3000
+    rng = np.random.default_rng(1)
+    schema = pa.schema([pa.field("chain", pa.int32(), nullable=False), pa.field("draw", pa.int32(), nullable=False),
+                        pa.field("a", pa.float64(), nullable=False), pa.field("b", pa.float64())])
+    t = pa.table({"chain": np.repeat(np.arange(3, dtype=np.int32), n // 3),
+                  "draw": np.tile(np.arange(n // 3, dtype=np.int32), 3),
+                  "a": rng.normal(size=n), "b": rng.normal(size=n)}, schema=schema)
+    img = image(t)
+    check_roundtrip(ctx, img)
+    check_roundtrip(ctx, img, ["b"])
+    check_roundtrip(ctx, img, ["b", "chain", "a"])
+
+
+def test_dictionary_fallback_and_large_pages(ctx):
+    # > 1 MB of distinct doubles: the writer abandons the dictionary mid-chunk (dict pages followed by PLAIN pages)
+    rng = np.random.default_rng(2)
+    n = 300_000
+    t = pa.table({"x": rng.normal(size=n), "small": rng.integers(0, 3000, n).astype(np.float64)})
+    img = image(t)
+    from mcmc_ref_hip.parquet import ParquetFile
+    with ParquetFile(img) as f:
+        encs = {p["encoding"] for p in f.pages() if p["column"] == 0 and p["kind"] == 0}
+    assert encs == {0, 8}, encs
+    check_roundtrip(ctx, img)
+    check_roundtrip(ctx, image(t, data_page_size=1 << 22, row_group_size=n))
+
+
+def test_snappy_back_references(ctx):
+    """Element kinds of the Snappy stream: long literals, overlapping copies (runs), 1/2-byte-offset copies and
+    copies that reach back beyond the 32 KB LDS window of the kernel."""
+    rng = np.random.default_rng(4)
+    period = rng.normal(size=5200)                               # 41.6 KB period: offsets > 32 KB
+    far = np.tile(period, 12)
+    n = far.size
+    zeros = np.zeros(n)
+    near = np.tile(rng.normal(size=37), n // 37 + 1)[:n]         # 296-byte period: short offsets
+    ramp = np.arange(n, dtype=np.float64)                        # shared high bytes: many short copies
+    t = pa.table({"far": far, "zeros": zeros, "near": near, "ramp": ramp, "idx": np.arange(n) % 1000})
+    for kw in (dict(use_dictionary=False), dict(use_dictionary=False, data_page_size=1 << 20), dict()):
+        check_roundtrip(ctx, image(t, **kw))
+
+
+def test_rejections(ctx):
+    from mcmc_ref_hip._ffi import McrError
+    from mcmc_ref_hip.parquet import read_columns
+    n = 1000
+    x = np.arange(n, dtype=np.float64)
+    with pytest.raises(McrError, match="null values"):
+        read_columns(ctx, image(pa.table({"x": pa.array([1.0, None, 3.0] * 100)})))
+    with pytest.raises(McrError, match="null values"):
+        read_columns(ctx, image(pa.table({"x": pa.array([None if i == 777 else float(i) for i in range(n)])}),
+                                data_page_version="2.0"))
+    with pytest.raises(McrError, match="codec"):
+        read_columns(ctx, image(pa.table({"x": x}), compression="zstd"))
+    with pytest.raises(McrError, match="encoding"):
+        read_columns(ctx, image(pa.table({"x": x}), use_dictionary=False, column_encoding={"x": "BYTE_STREAM_SPLIT"}))
+    with pytest.raises(McrError, match="physical type"):
+        read_columns(ctx, image(pa.table({"s": pa.array(["a", "b"])})), ["s"])
+    # a corrupted Snappy payload is reported, not decoded into garbage silently
+    img = bytearray(image(pa.table({"x": np.tile(np.arange(50.0), 200)}), use_dictionary=False))
+    from mcmc_ref_hip.parquet import ParquetFile
+    with ParquetFile(bytes(img)) as f:
+        pg = f.pages()[0]
+    img[pg["payload_offset"]] ^= 0x55                       # breaks the length preamble
+    with pytest.raises(McrError, match="Snappy"):
+        read_columns(ctx, bytes(img))
+    # the context keeps working after errors
+    check_roundtrip(ctx, image(pa.table({"x": x})))
+    # empty table
+    got = read_columns(ctx, image(pa.table({"x": pa.array([], pa.float64())})))
+    assert got["x"].shape == (0,)
+
+
+def test_packaged_files_match_the_reference_reader(ctx):
+    """Real corpus files (parquet-cpp-arrow 23.0.0) against the draws the reference's own reader produced
+    (tests/golden/models/*.npz, written by tests/golden/make_golden.py) and against pyarrow here."""
+    from mcmc_ref_hip.parquet import read_draws
+    for name in ("wells_data-wells_dist", "radon_pooled"):
+        path = GOLDEN / "parquet" / f"{name}.draws.parquet"
+        check_roundtrip(ctx, path.read_bytes())
+        draws, params, rec = load_model(name)                 # [P][C][N]
+        d = read_draws(ctx, path)
+        assert d.params == params and d.rectangular
+        assert d.tensor.targs[1:4] == (draws.shape[1], draws.shape[2], draws.shape[0])
+        assert np.array_equal(bits(d.to_host().reshape(draws.shape)), bits(draws))
+        # straight into the statistics, no host round trip of the draws
+        got = ctx.enqueue(d.tensor, min_chains=1)
+        ctx.wait()
+        exp = ctx.summarize(draws, "pcn", min_chains=1)
+        for k in ("mean", "std", "q", "rhat", "ess_bulk", "ess_tail"):
+            assert np.array_equal(bits(got.result()[k]), bits(exp[k])), (name, k)
+        d.free()
+
+
+def test_unordered_rows_and_batched_files(ctx):
+    from mcmc_ref_hip.convert import table_to_tensor
+    from mcmc_ref_hip.parquet import read_draws_many
+    rng = np.random.default_rng(9)
+    imgs, tables = [], []
+    for k, (C, N, P) in enumerate([(4, 500, 3), (10, 100, 7), (2, 1000, 1), (4, 250, 5)]):
+        cols = {"chain": np.repeat(np.arange(C), N), "draw": np.tile(np.arange(N), C)}
+        for p in range(P):
+            cols[f"theta[{p + 1}]"] = rng.normal(size=C * N)
+        t = pa.table(cols)
+        if k % 2 == 1:                                         # rows shuffled: needs the (chain, draw) gather
+            t = t.take(pa.array(rng.permutation(C * N)))
+        tables.append(t)
+        imgs.append(image(t, row_group_size=600 if k == 0 else None))
+    out = read_draws_many(ctx, imgs)
+    for t, d in zip(tables, out):
+        params = [n for n in t.column_names if n not in ("chain", "draw")]
+        x, counts = table_to_tensor(t, params)
+        assert d.params == params and np.array_equal(d.counts, counts)
+        assert np.array_equal(bits(d.to_host()), bits(x))
+        d.free()
+    # ragged chains: decoded, but no rectangular tensor
+    t = pa.table({"chain": [0] * 5 + [1] * 3, "draw": list(range(5)) + list(range(3)), "x": np.arange(8.0)})
+    d = read_draws_many(ctx, [image(t)])[0]
+    assert d.tensor is None and list(d.counts) == [5, 3] and np.array_equal(d.to_host()[0], np.arange(8.0))
+    d.free()
