@@ -306,10 +306,20 @@ __device__ __forceinline__ void pq_error(int* err, int code, int page)
 
 // ---- Snappy (raw format) -----------------------------------------------------------------------
 // One wavefront per page; the element stream is parsed by all lanes in lock step from an LDS window of the input,
-// and the lanes share each literal / copy.  The last kRing output bytes are mirrored in LDS so that back references
-// (always within 64 KB in practice, almost always within a few KB) never wait on global memory; farther ones read
-// the output back behind a workgroup fence.
-constexpr int kRing = 32768, kInWin = 4096;
+// and the lanes share each literal / copy.  The output is assembled in an LDS ring (the last kRing bytes) and
+// flushed to global memory in 8 KB pieces with 16-byte stores, so an element costs LDS latency only: no global
+// store, and no wait for one, sits between two elements.  Back references (always within 64 KB in practice, almost
+// always within a few KB) read the ring; farther ones flush and read the output back behind a workgroup fence.
+// Literals longer than 64 bytes go from the input straight to global memory (and the ring) 16 bytes per lane.
+constexpr int kRing = 32768, kInWin = 4096, kFlush = 8192;
+
+// Orders LDS traffic between the lanes of ONE wavefront: LDS executes a wave's instructions in issue order, so only
+// the compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restrict__ stage, unsigned char* scratch,
                                                   const PageDev* __restrict__ pages, const int* __restrict__ list,
@@ -321,26 +331,57 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
     const PageDev pg = pages[pi];
     const int lane = threadIdx.x;
     const unsigned char* src = stage + pg.src_off + pg.lvl_bytes;
-    unsigned char* dst = scratch + pg.dst_off;
+    unsigned char* dst = scratch + pg.dst_off;          // 16-byte aligned
     const u32 n_in = pg.comp_size, n_out = pg.uncomp_size;
+    constexpr u32 RM = kRing - 1;
+    auto uni = [](u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); };   // wave-uniform value -> SGPR
     // preamble: uncompressed length
     u32 ip = 0, ulen = 0;
     for (int s = 0; s < 35 && ip < n_in; s += 7) { const u32 b = src[ip++]; ulen |= (b & 0x7F) << s; if (!(b & 0x80)) break; }
-    if (ulen != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); return; }
-    i64 win = -(i64)kInWin * 2;          // input offset of inb[0]; the window is [win, win + kInWin)
+    ip = uni(ip);
+    if (uni(ulen) != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); return; }
+    i64 win = -(i64)kInWin * 2;          // input offset of inb[0]; the LDS window is [win, win + kInWin)
     const uintptr_t src_a = (uintptr_t)src;
-    u32 op = 0;
+    u32 op = 0, flushed = 0;             // output bytes produced / already in global memory
     bool bad = false;
-    while (ip < n_in && !bad) {
-        if ((i64)ip < win || (i64)ip + 5 > win + kInWin) {             // refill: 16-byte aligned global loads
-            win = (i64)ip - (i64)((src_a + ip) & 15);
-            __syncthreads();
+    // Register window: lane l holds input byte wpos + l, so the element headers are parsed with v_readlane and
+    // scalar ALU only -- no LDS round trip per element.
+    u32 wbyte = 0, wpos = 0; bool whave = false;
+    // The ring write of an element is issued one element late (after the NEXT element has been parsed), so the
+    // latency of the LDS read that feeds it overlaps that parse.  LDS executes in order: the late write still lands
+    // before any later read.
+    u32 pval = 0, ppos = 0, plen = 0;
+    auto commit = [&]() {
+        if (plen) { if (lane < (int)plen) ring[(ppos + lane) & RM] = (unsigned char)pval; plen = 0; }
+    };
+    auto flush = [&](u32 upto) {         // ring -> dst for [flushed, upto); upto - flushed <= kRing; nothing pending
+        wave_sync();
+        u32 a = flushed;
+        const u32 h = min(upto - a, (16u - (a & 15)) & 15);
+        if (lane < (int)h) dst[a + lane] = ring[(a + lane) & RM];
+        a += h;
+        const u32 nv = (upto - a) >> 4;
+        for (u32 v = lane; v < nv; v += 64) *(uint4*)(dst + a + 16 * v) = *(const uint4*)(ring + ((a + 16 * v) & RM));
+        a += 16 * nv;
+        if (lane < (int)(upto - a)) dst[a + lane] = ring[(a + lane) & RM];
+        flushed = upto;
+    };
+
+    while (ip < n_in) {
+        // input windows: LDS covers [ip, ip + 72) (header + a short literal), registers cover the 5 header bytes
+        if ((i64)ip < win || (i64)ip + 72 > win + kInWin) {
+            win = (i64)ip - (i64)((src_a + ip) & 15);                    // 16-byte aligned global loads
+            wave_sync();
             for (int o = lane * 16; o < kInWin; o += 64 * 16)
                 *(uint4*)(inb + o) = *(const uint4*)(src + win + o);     // reads past n_in stay inside the padded stage
-            __syncthreads();
+            wave_sync();
+            whave = false;
         }
-        const unsigned char* q = inb + ((i64)ip - win);
-        const u32 tag = q[0], b1 = q[1], b2 = q[2], b3 = q[3], b4 = q[4];
+        if (!whave || ip + 5 > wpos + 64) { wbyte = inb[(i64)ip - win + lane]; wpos = ip; whave = true; }
+        const int r = (int)(ip - wpos);
+        const u32 tag = (u32)__builtin_amdgcn_readlane((int)wbyte, r), b1 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 1),
+                  b2 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 2), b3 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 3),
+                  b4 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 4);
         if ((tag & 3) == 0) {                                            // literal
             u32 len = tag >> 2, hdr = 1;
             if (len >= 60) {
@@ -350,15 +391,16 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
             }
             len += 1; ip += hdr;
             if (ip > n_in || len > n_in - ip || len > n_out - op) { bad = true; break; }
-            if (len <= 64 && (i64)ip + len <= win + kInWin) {            // short literal inside the window
-                if (lane < (int)len) {
-                    const unsigned char b = inb[(i64)ip - win + lane];
-                    ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b;
-                }
-            } else {                                                     // long literal: 16 bytes per lane and step
+            if (len <= 64) {                                             // short literal: LDS window -> ring
+                commit();
+                if (lane < (int)len) pval = inb[(i64)ip - win + lane];
+                ppos = op; plen = len;
+            } else {                                                     // long literal: input -> global + ring
+                commit();
+                flush(op);
                 const unsigned char* s = src + ip;
                 const u32 h = min(len, (16u - (op & 15)) & 15);
-                if (lane < (int)h) { const unsigned char b = s[lane]; ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b; }
+                if (lane < (int)h) { const unsigned char b = s[lane]; ring[(op + lane) & RM] = b; dst[op + lane] = b; }
                 const unsigned char* s2 = s + h;
                 const u32 nv = (len - h) >> 4, o2 = op + h;
                 const uintptr_t a2 = (uintptr_t)s2;
@@ -370,10 +412,11 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
                     x.x = __funnelshift_r(w0, w1, sh); x.y = __funnelshift_r(w1, w2, sh);
                     x.z = __funnelshift_r(w2, w3, sh); x.w = __funnelshift_r(w3, w4, sh);
                     *(uint4*)(dst + o2 + 16 * v) = x;
-                    *(uint4*)(ring + ((o2 + 16 * v) & (kRing - 1))) = x;
+                    *(uint4*)(ring + ((o2 + 16 * v) & RM)) = x;
                 }
                 const u32 tl = (len - h) & 15, o3 = o2 + 16 * nv;
-                if (lane < (int)tl) { const unsigned char b = s2[16 * nv + lane]; ring[(o3 + lane) & (kRing - 1)] = b; dst[o3 + lane] = b; }
+                if (lane < (int)tl) { const unsigned char b = s2[16 * nv + lane]; ring[(o3 + lane) & RM] = b; dst[o3 + lane] = b; }
+                flushed = op + len;
             }
             ip += len; op += len;
         } else {                                                         // copy
@@ -382,21 +425,24 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
             else if ((tag & 3) == 2) { len = (tag >> 2) + 1; off = b1 | (b2 << 8); ip += 3; }
             else { len = (tag >> 2) + 1; off = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); ip += 5; }
             if (off == 0 || off > op || len > n_out - op || ip > n_in) { bad = true; break; }
-            unsigned char b = 0;
             const u32 k = (off >= len) ? (u32)lane : (u32)lane % off;    // overlapping copies repeat the last `off` bytes
+            commit();
+            wave_sync();
             if (off <= kRing) {
-                if (lane < (int)len) b = ring[(op - off + k) & (kRing - 1)];
-            } else {
+                if (lane < (int)len) pval = ring[(op - off + k) & RM];
+            } else {                                                     // beyond the ring: read the output back
+                flush(op);
                 __threadfence_block();
                 __syncthreads();
-                if (lane < (int)len) b = ((volatile unsigned char*)dst)[op - off + k];
+                if (lane < (int)len) pval = ((volatile unsigned char*)dst)[op - off + k];
             }
-            __syncthreads();
-            if (lane < (int)len) { ring[(op + lane) & (kRing - 1)] = b; dst[op + lane] = b; }
+            ppos = op; plen = len;
             op += len;
         }
-        __syncthreads();
+        if ((op ^ flushed) >= (u32)kFlush) { commit(); flush(op & ~(u32)(kFlush - 1)); }   // crossed an 8 KB boundary
+        wave_sync();
     }
+    if (!bad) { commit(); flush(op); }
     if (bad || op != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); }
 }
 

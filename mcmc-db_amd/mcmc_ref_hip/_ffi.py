@@ -317,9 +317,10 @@ class Context:
         self._check(fn(self.handle, ptr, *targs, int(min_chains), _as_dp(qs), qs.size, C.byref(bufs.struct)))
         return bufs.result()
 
-    def enqueue(self, t: DeviceTensor, min_chains: int = 4, quantiles=(0.05, 0.5, 0.95)) -> SummaryBuffers:
+    def enqueue(self, t: DeviceTensor, min_chains: int = 4, quantiles=(0.05, 0.5, 0.95),
+                diagnostics: bool = True) -> SummaryBuffers:
         qs = self._quantiles(quantiles)
-        bufs = SummaryBuffers(t.targs[3], qs.size)
+        bufs = SummaryBuffers(t.targs[3], qs.size, diagnostics)
         self._check(self.lib.mcr_summarize_enqueue(self.handle, t.buf.ptr, *t.targs, int(min_chains), _as_dp(qs),
                                                    qs.size, C.byref(bufs.struct)))
         self._pending.append(bufs)

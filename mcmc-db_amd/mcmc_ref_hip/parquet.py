@@ -106,18 +106,64 @@ def decode(ctx: "_ffi.Context", requests: Sequence[tuple[ParquetFile, int, int, 
 def _layout(chain: np.ndarray, draw: np.ndarray):
     """(chain ids, order or None, draws per chain) -- the integer bookkeeping of `_chains_from_table`
     (src/mcmc_ref/convert.py:150-161); same rule as convert.chain_layout."""
+    if chain.size:
+        dc = np.diff(chain)
+        if np.all(dc >= 0):                           # chain-major file (every packaged one): no sort needed
+            cut = np.flatnonzero(dc) + 1
+            starts = np.concatenate([[0], cut])
+            counts = np.diff(np.concatenate([starts, [chain.size]]))
+            dd = np.diff(draw)
+            dd[cut - 1] = 0                           # steps across a chain boundary do not count
+            if np.all(dd >= 0):
+                return chain[starts].copy(), None, counts
     ids, counts = np.unique(chain, return_counts=True)
-    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
-    already = chain.size == 0 or (np.all(np.diff(chain) >= 0) and
-                                  all(np.all(np.diff(draw[s:s + n]) >= 0) for s, n in zip(starts, counts)))
-    order = None if already else np.lexsort((draw, chain))
+    order = None if chain.size == 0 else np.lexsort((draw, chain))
     return ids, order, counts
+
+
+class _Arena:
+    """One device allocation shared by the models of a batch (hipMalloc / hipFree cost ~0.1 ms each, which
+    would dominate a 57-file corpus pass); freed when the last view is."""
+
+    def __init__(self, ctx, nbytes: int):
+        self.buf = DeviceBuffer(ctx, max(nbytes, 8))
+        self.refs = 0
+
+    def view(self, offset: int, nbytes: int) -> "_View":
+        self.refs += 1
+        return _View(self, offset, nbytes)
+
+    def release(self):
+        self.refs -= 1
+        if self.refs <= 0:
+            self.buf.free()
+
+
+class _View:
+    """Slice of an arena with DeviceBuffer's interface (ptr / download / free)."""
+
+    def __init__(self, arena: _Arena, offset: int, nbytes: int):
+        self.arena, self.ctx, self.nbytes = arena, arena.buf.ctx, nbytes
+        self.ptr = C.c_void_p(arena.buf.ptr.value + offset)
+
+    def download(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            self.ctx._check(self.ctx.lib.mcr_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), self.ptr,
+                                                        out.nbytes))
+        return out
+
+    def free(self):
+        if self.arena is not None:
+            self.arena.release()
+            self.arena = None
+            self.ptr = C.c_void_p()
 
 
 class DeviceDraws:
     """Draws of one model in HBM: `tensor` is [P][M] f64 in (chain, draw) order; counts = draws per chain."""
 
-    def __init__(self, tensor: DeviceTensor | None, buf: DeviceBuffer, params: list[str], chain_ids: np.ndarray,
+    def __init__(self, tensor: DeviceTensor | None, buf, params: list[str], chain_ids: np.ndarray,
                  counts: np.ndarray):
         self.tensor, self.buf, self.params, self.chain_ids, self.counts = tensor, buf, params, chain_ids, counts
 
@@ -140,30 +186,41 @@ def read_draws_many(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Ite
     owned = [not isinstance(s, ParquetFile) for s in sources]
     try:
         reqs, plan, bufs = [], [], []
+        wants, sizes = [], []
         for k, f in enumerate(files):
             want = list(params[k]) if params is not None and params[k] is not None else \
                 [n for n, t in zip(f.column_names, f.column_types) if n not in ("chain", "draw") and t in NUMERIC]
+            wants.append(want)
+            sizes.append((-(-len(want) * f.num_rows * 8 // 256)) * 256)       # 256-byte aligned slices
+        arena = _Arena(ctx, sum(sizes))
+        id_rows = sum(f.num_rows for f in files)
+        ids_all = DeviceBuffer(ctx, max(2 * id_rows * 8, 8))
+        off = ioff = 0
+        for f, want, size in zip(files, wants, sizes):
             cols = [f.index(n) for n in want]
             M = f.num_rows
-            buf = DeviceBuffer(ctx, max(len(cols) * M * 8, 8))
-            ids = DeviceBuffer(ctx, max(2 * M * 8, 8))
-            base, ibase = buf.ptr.value, ids.ptr.value
+            buf = arena.view(off, len(cols) * M * 8)
+            base, ibase = buf.ptr.value, ids_all.ptr.value + ioff * 8
             for j, c in enumerate(cols):
                 reqs.append((f, c, MCR_PQ_F64, base + j * M * 8))
             reqs.append((f, f.index("chain"), MCR_PQ_I64, ibase))
             reqs.append((f, f.index("draw"), MCR_PQ_I64, ibase + M * 8))
-            plan.append((want, M, buf, ids))
-            bufs += [buf, ids]
+            plan.append((want, M, buf, ioff))
+            bufs.append(buf)
+            off += size
+            ioff += 2 * M
         try:
             decode(ctx, reqs)
+            ids_host = ids_all.download(np.int64, 2 * id_rows)
         except Exception:
             for b in bufs:
                 b.free()
             raise
+        finally:
+            ids_all.free()
         out = []
-        for want, M, buf, ids in plan:
-            cd = ids.download(np.int64, 2 * M)
-            ids.free()
+        for want, M, buf, ioff in plan:
+            cd = ids_host[ioff:ioff + 2 * M]
             chain_ids, order, counts = _layout(cd[:M], cd[M:])
             if order is not None and want and M:
                 dst = DeviceBuffer(ctx, len(want) * M * 8)
@@ -206,3 +263,85 @@ def read_columns(ctx: "_ffi.Context", source, columns: Iterable[str] | None = No
     finally:
         if not isinstance(source, ParquetFile):
             f.close()
+
+
+def _entry(r: dict, i: int, qs, diagnostics: bool) -> dict[str, float]:
+    e = {"mean": float(r["mean"][i]), "std": float(r["std"][i])}
+    for q, v in zip(qs, r["q"][i]):
+        e[f"q{int(q * 100)}"] = float(v)
+    if diagnostics:
+        e.update(rhat=float(r["rhat"][i]), ess_bulk=float(r["ess_bulk"][i]), ess_tail=float(r["ess_tail"][i]))
+    return e
+
+
+def summarize_files(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Iterable[str] | None] | None = None, *,
+                    min_chains: int = 4, quantiles=(0.05, 0.5, 0.95), diagnostics: bool = True
+                    ) -> list[dict[str, dict[str, float]]]:
+    """File images -> per-parameter statistics without the draws ever visiting host memory decoded:
+    one batched decode, then the models are pipelined through the summarise lanes (rolling window).
+
+    diagnostics=False is `Backend.stats` (pooled mean / std / quantiles, any chain structure);
+    diagnostics=True adds rhat / ess_bulk / ess_tail and needs equal-length chains (what
+    `convert._compute_diagnostics` + `Backend.stats` give for the same file).
+    """
+    qs = list(quantiles)
+    models = read_draws_many(ctx, sources, params)
+    try:
+        pending = []
+        for d in models:
+            P, M = len(d.params), int(d.counts.sum())
+            if P == 0:
+                pending.append(None)
+                continue
+            if diagnostics:
+                if len(d.counts) < min_chains:
+                    raise ValueError(f"R-hat diagnostics require at least {min_chains} chains; got {len(d.counts)} chain(s)")
+                if d.tensor is None:                 # ragged chains: pooled stats now, one pipeline per parameter below
+                    t = DeviceTensor(ctx, d.buf, (MCR_F64, 1, M, P, M, 1, M))
+                    if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
+                        ctx.wait_one()
+                    pending.append(ctx.enqueue(t, min_chains=1, quantiles=qs, diagnostics=False))
+                    continue
+                t = d.tensor
+            else:
+                if M == 0:
+                    raise ValueError("cannot compute stats of empty columns")
+                t = DeviceTensor(ctx, d.buf, (MCR_F64, 1, M, P, M, 1, M))
+            if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
+                ctx.wait_one()
+            try:
+                pending.append(ctx.enqueue(t, min_chains=min_chains if diagnostics else 1, quantiles=qs,
+                                           diagnostics=diagnostics))
+            except McrError as exc:
+                raise ValueError(exc.message) from exc
+        try:
+            ctx.wait()
+        except McrError as exc:
+            raise ValueError(exc.message) from exc
+        out = []
+        for d, b in zip(models, pending):
+            r = b.result() if b is not None else None
+            if r is not None and diagnostics and d.tensor is None:
+                x = d.to_host()
+                off = np.concatenate([[0], np.cumsum(d.counts)])
+                r = dict(r)
+                for k in ("rhat", "ess_bulk", "ess_tail"):
+                    r[k] = np.full(len(d.params), np.nan)
+                for i in range(len(d.params)):
+                    try:
+                        g = ctx.diagnose_chains([x[i, off[c]:off[c + 1]] for c in range(len(d.counts))],
+                                                min_chains=min_chains)
+                    except McrError as exc:
+                        raise ValueError(exc.message) from exc
+                    for k in ("rhat", "ess_bulk", "ess_tail"):
+                        r[k][i] = g[k]
+            out.append({p: _entry(r, i, qs, diagnostics) for i, p in enumerate(d.params)})
+        return out
+    finally:
+        try:
+            if ctx.inflight:
+                ctx.wait()
+        except McrError:
+            pass
+        for d in models:
+            d.free()

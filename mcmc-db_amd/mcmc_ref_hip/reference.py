@@ -6,6 +6,7 @@ Same surface as the reference's src/mcmc_ref/reference.py:15-122 (`list_models`,
 """
 from __future__ import annotations
 
+import os
 from collections.abc import Mapping, Sequence
 
 from . import convert
@@ -34,11 +35,41 @@ def _table_and_params(store: DataStore, model: str, params):
     return table, list(params)
 
 
+def _native_reader() -> bool:
+    """The "hip" backend reads `draws/<model>.draws.parquet` with the library's own Parquet ingest (decode on the
+    GPU, no pyarrow) unless MCMC_REF_HIP_READER=arrow asks for the reference's pyarrow route."""
+    return os.environ.get("MCMC_REF_HIP_READER", "native").lower() != "arrow"
+
+
+def _native_summaries(store: DataStore, models: Sequence[str], params, *, diagnostics: bool, min_chains: int = 4):
+    from . import _ffi, parquet
+    ctx = _ffi.default_context()
+    paths = [store.resolve_draws_path(m) for m in models]
+    try:
+        return parquet.summarize_files(ctx, paths, [params] * len(paths), min_chains=min_chains,
+                                       diagnostics=diagnostics)
+    except KeyError as exc:                      # unknown column: the same exception type pyarrow's path ends in
+        raise KeyError(str(exc)) from exc
+
+
 def stats(model: str, params: Sequence[str] | None = None, backend: str = "hip", quantile_mode: str = "exact",
           store: DataStore | None = None) -> dict[str, dict[str, float]]:
     """Summary statistics (mean, std, q5, q50, q95) of a model's reference draws."""
-    table, params = _table_and_params(store or DataStore(), model, params)
+    store = store or DataStore()
+    if backend == "hip" and _native_reader():
+        get_backend(backend)                     # ImportError without the library / a device, as for any backend
+        return _native_summaries(store, [model], params, diagnostics=False)[0]
+    table, params = _table_and_params(store, model, params)
     return get_backend(backend).stats(table, params, quantile_mode=quantile_mode)
+
+
+def summaries_for_models(models: Sequence[str], store: DataStore | None = None, min_chains: int = 4
+                         ) -> dict[str, dict[str, dict[str, float]]]:
+    """All statistics of many models from one batched Parquet decode + pipelined kernel passes
+    (an addition; the reference loops `stats` / `diagnostics_for_model` per model)."""
+    store = store or DataStore()
+    out = _native_summaries(store, list(models), None, diagnostics=True, min_chains=min_chains)
+    return dict(zip(models, out))
 
 
 def draws(model: str, params: Sequence[str] | None = None, chains: Sequence[int] | None = None,
@@ -64,6 +95,9 @@ def diagnostics_for_model(model: str, params: Sequence[str] | None = None,
     diag = meta.get("diagnostics")
     if isinstance(diag, dict) and diag:
         return diag if params is None else {p: diag[p] for p in params if p in diag}
+    if _native_reader():
+        full = _native_summaries(store, [model], params, diagnostics=True)[0]
+        return {p: {k: v[k] for k in ("rhat", "ess_bulk", "ess_tail")} for p, v in full.items()}
     table, params = _table_and_params(store, model, params)
     return convert._compute_diagnostics(table, params)
 
@@ -71,7 +105,10 @@ def diagnostics_for_model(model: str, params: Sequence[str] | None = None,
 def summary_for_model(model: str, params: Sequence[str] | None = None, store: DataStore | None = None,
                       min_chains: int = 4) -> dict[str, dict[str, float]]:
     """mean, std, q5, q50, q95, rhat, ess_bulk, ess_tail per parameter from one pass of the kernels."""
-    table, params = _table_and_params(store or DataStore(), model, params)
+    store = store or DataStore()
+    if _native_reader():
+        return _native_summaries(store, [model], params, diagnostics=True, min_chains=min_chains)[0]
+    table, params = _table_and_params(store, model, params)
     return convert.summarize_table(table, params, min_chains=min_chains)
 
 

@@ -204,3 +204,44 @@ def test_unordered_rows_and_batched_files(ctx):
     d = read_draws_many(ctx, [image(t)])[0]
     assert d.tensor is None and list(d.counts) == [5, 3] and np.array_equal(d.to_host()[0], np.arange(8.0))
     d.free()
+
+
+def test_reference_api_native_reader_equals_arrow_reader(ctx, tmp_path, monkeypatch):
+    """`reference.stats / diagnostics_for_model / summary_for_model` over a store: the native ingest (default)
+    and the pyarrow route (MCMC_REF_HIP_READER=arrow) feed the same kernels and must agree bit for bit."""
+    from mcmc_ref_hip import reference
+    from mcmc_ref_hip.store import DataStore
+    root = tmp_path / "pkg"
+    (root / "draws").mkdir(parents=True)
+    (root / "meta").mkdir()
+    names = []
+    for name in ("wells_data-wells_dist", "radon_pooled"):
+        (root / "draws" / f"{name}.draws.parquet").write_bytes((GOLDEN / "parquet" / f"{name}.draws.parquet").read_bytes())
+        names.append(name)
+    rng = np.random.default_rng(12)
+    t = pa.table({"chain": [0] * 40 + [1] * 30 + [2] * 35 + [3] * 40, "draw": list(range(40)) + list(range(30)) +
+                  list(range(35)) + list(range(40)), "a": rng.normal(size=145), "b": rng.normal(size=145)})
+    pq.write_table(t, root / "draws" / "ragged.draws.parquet")
+    st = DataStore(local_root=tmp_path / "none", packaged_root=root)
+    res = {}
+    for reader in ("native", "arrow"):
+        monkeypatch.setenv("MCMC_REF_HIP_READER", reader)
+        res[reader] = {
+            "stats": {m: reference.stats(m, store=st) for m in names + ["ragged"]},
+            "stats_sub": reference.stats("radon_pooled", params=["sigma"], store=st),
+            "diag": {m: reference.diagnostics_for_model(m, store=st) for m in names + ["ragged"]},
+            "summ": {m: reference.summary_for_model(m, store=st) for m in names},
+        }
+    assert res["native"] == res["arrow"]
+    assert list(res["native"]["stats_sub"]) == ["sigma"]
+    monkeypatch.setenv("MCMC_REF_HIP_READER", "native")
+    both = reference.summaries_for_models(names, store=st)
+    assert both == res["native"]["summ"]
+    # and the packaged goldens of the reference (meta.json diagnostics restated in tests/golden/models/*.json)
+    for name in names:
+        _, params, rec = load_model(name)
+        for p in params:
+            for k in ("rhat", "ess_bulk", "ess_tail"):
+                assert both[name][p][k] == pytest.approx(rec["meta_diagnostics"][p][k], rel=1e-6)
+    with pytest.raises(KeyError):
+        reference.stats("radon_pooled", params=["nope"], store=st)
