@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's measurement artefacts on the GPU box into gpurun_out/prof/ (copy what is to be judged into
+# profiles/).  usage (through gpurun):  bash tools/collect_profiles.sh <tag>
+#   1. bench.py default run (the line the driver will reproduce)
+#   2. rocprofv3 --kernel-trace --stats of the same bench with MCR_LANES=1 (kernels alone, as the HIP-event pass times them)
+#   3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, counters only) -> per-kernel HBM traffic per launch
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof
+mkdir -p "$OUT"
+cd "$REPO" || exit 1
+python bench.py > "$OUT/${TAG}_c1_bench.json" 2> "$OUT/${TAG}_c1_bench.err" || echo "bench failed"
+python bench.py --workload corpus --steps 200 --no-moments > "$OUT/${TAG}_corpus_bench.json" 2>> "$OUT/${TAG}_c1_bench.err" || echo "corpus bench failed"
+python tools/ingest_bench.py 5 > "$OUT/${TAG}_ingest_parquet.json" 2> "$OUT/${TAG}_ingest.err" || echo "ingest bench failed"
+cd /tmp && export TMPDIR=/tmp
+export MCR_LANES=1
+BENCH="$REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-moments"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- python3 $BENCH > "$OUT/${TAG}_rocprof_bench_lanes1.json" 2> /tmp/prof_kt.err
+find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_c1_kernel_stats_lanes1.csv" \;
+SHORT="$REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-moments --no-validate"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o f -- python3 $SHORT > /dev/null 2> /tmp/prof_f.err
+find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_fetch_c1.csv" \;
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python3 $SHORT > /dev/null 2> /tmp/prof_w.err
+find /tmp/prof_w -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_write_c1.csv" \;
+cd "$REPO" && python tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch_c1.csv" "$OUT/${TAG}_pmc_write_c1.csv" > "$OUT/pmc_traffic.json"
+tail -3 /tmp/prof_kt.err /tmp/prof_f.err; ls -la "$OUT"
