@@ -160,7 +160,7 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
             valid = valid and ok
         t.free()
     local = np.concatenate(recs) if recs else np.empty((0, shard.RECORD_DOUBLES))
-    allrec = shard.gather_records(local, dist, device=dist_dev)
+    allrec = shard.gather_records(local, dist, device=dist_dev, force=os.environ.get("MCR_BENCH_FORCE_DIST") == "1")
     valid = valid and allrec.shape[0] == 460
     if dist is not None:
         flag = torch.tensor([1.0 if valid else 0.0], device=dist_dev)
@@ -192,7 +192,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dist = torch = None
     dist_dev = None
-    if world > 1:
+    # MCR_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so that the RCCL calls of the
+    # N > 1 path (barrier, all_reduce, all_gather_into_tensor on device tensors) can be exercised on a 1-GPU box.
+    force_dist = os.environ.get("MCR_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         if a.dist_backend == "nccl":
@@ -277,7 +280,7 @@ def main():
     if dist is not None:
         from mcmc_ref_hip import shard
         mine = shard.pack_records(got, rank, C, N)
-        allrec = shard.gather_records(mine, dist, device=dist_dev)
+        allrec = shard.gather_records(mine, dist, device=dist_dev, force=force_dist)
         sel = allrec[allrec[:, shard.RECORD_FIELDS.index("model_idx")] == rank]
         gathered_ok = allrec.shape[0] == world * P and np.array_equal(sel, mine, equal_nan=True)
 

@@ -50,11 +50,12 @@ def pack_records(summary: dict, model_idx: int, n_chains: int, n_draws: int) -> 
     return rec
 
 
-def gather_records(local: np.ndarray, dist=None, device=None) -> np.ndarray:
+def gather_records(local: np.ndarray, dist=None, device=None, force: bool = False) -> np.ndarray:
     """all_gather of every rank's [n_r][16] records -> [sum n_r][16] on every rank, ordered by
-    (model_idx, param_idx).  `dist` is torch.distributed (initialised) or None for a single process."""
+    (model_idx, param_idx).  `dist` is torch.distributed (initialised) or None for a single process.
+    force=True runs the collective even for a world of one (exercises the RCCL path on a 1-GPU box)."""
     local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, RECORD_DOUBLES)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         out = local
     else:
         import torch
