@@ -32,12 +32,12 @@ constexpr int kMaxGridY = 65535;
 
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
-    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_CHAIN_STATS, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
+    K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
     K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
-    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_chain_stats", "k_splitters",
+    "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_splitters",
     "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable",
     "k_pq_snappy", "k_pq_decode", "k_gather_rows"};
 
