@@ -305,13 +305,19 @@ __device__ __forceinline__ void pq_error(int* err, int code, int page)
 }
 
 // ---- Snappy (raw format) -----------------------------------------------------------------------
-// One wavefront per page; the element stream is parsed by all lanes in lock step from an LDS window of the input,
-// and the lanes share each literal / copy.  The output is assembled in an LDS ring (the last kRing bytes) and
-// flushed to global memory in 8 KB pieces with 16-byte stores, so an element costs LDS latency only: no global
-// store, and no wait for one, sits between two elements.  Back references (always within 64 KB in practice, almost
-// always within a few KB) read the ring; farther ones flush and read the output back behind a workgroup fence.
-// Literals longer than 64 bytes go from the input straight to global memory (and the ring) 16 bytes per lane.
+// One wavefront per page.  A Snappy stream is a chain of elements whose boundaries are only known by walking it, so
+// the kernel works in batches of 64 input bytes:
+//   1. every lane decodes "the element that would start at my byte" (type, header size, lengths, offset);
+//   2. a scalar walk over those candidates (v_readlane + s_add per element, no memory access) marks the real
+//      element starts; a wave scan of their output lengths gives every element its output position;
+//   3. all literal bytes of the batch go to the output in ONE step (each lane owns one input byte);
+//   4. the copies run in stream order, all lanes sharing one copy.
+// The output is assembled in an LDS ring (the last kRing bytes) and flushed to global memory in 8 KB pieces with
+// 16-byte stores; back references (always within 64 KB in practice, almost always within a few KB) read the ring,
+// farther ones flush and read the output back behind a workgroup fence.  Literals that do not fit the window go
+// alone: up to 64 bytes through LDS, longer ones from the input straight to global memory at 16 bytes per lane.
 constexpr int kRing = 32768, kInWin = 4096, kFlush = 8192;
+constexpr int kBatchOut = 64 * 64 + 64;      // most output bytes one batch can produce
 
 // Orders LDS traffic between the lanes of ONE wavefront: LDS executes a wave's instructions in issue order, so only
 // the compiler has to be kept from moving accesses across this point.
@@ -335,6 +341,7 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
     const u32 n_in = pg.comp_size, n_out = pg.uncomp_size;
     constexpr u32 RM = kRing - 1;
     auto uni = [](u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); };   // wave-uniform value -> SGPR
+    auto rl = [](u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); };
     // preamble: uncompressed length
     u32 ip = 0, ulen = 0;
     for (int s = 0; s < 35 && ip < n_in; s += 7) { const u32 b = src[ip++]; ulen |= (b & 0x7F) << s; if (!(b & 0x80)) break; }
@@ -344,17 +351,8 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
     const uintptr_t src_a = (uintptr_t)src;
     u32 op = 0, flushed = 0;             // output bytes produced / already in global memory
     bool bad = false;
-    // Register window: lane l holds input byte wpos + l, so the element headers are parsed with v_readlane and
-    // scalar ALU only -- no LDS round trip per element.
-    u32 wbyte = 0, wpos = 0; bool whave = false;
-    // The ring write of an element is issued one element late (after the NEXT element has been parsed), so the
-    // latency of the LDS read that feeds it overlaps that parse.  LDS executes in order: the late write still lands
-    // before any later read.
-    u32 pval = 0, ppos = 0, plen = 0;
-    auto commit = [&]() {
-        if (plen) { if (lane < (int)plen) ring[(ppos + lane) & RM] = (unsigned char)pval; plen = 0; }
-    };
-    auto flush = [&](u32 upto) {         // ring -> dst for [flushed, upto); upto - flushed <= kRing; nothing pending
+
+    auto flush = [&](u32 upto) {         // ring -> dst for [flushed, upto); upto - flushed <= kRing
         wave_sync();
         u32 a = flushed;
         const u32 h = min(upto - a, (16u - (a & 15)) & 15);
@@ -368,35 +366,47 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
     };
 
     while (ip < n_in) {
-        // input windows: LDS covers [ip, ip + 72) (header + a short literal), registers cover the 5 header bytes
-        if ((i64)ip < win || (i64)ip + 72 > win + kInWin) {
+        // LDS input window covers [ip, ip + 136): 64 candidate headers of 5 bytes, or a header + a 64-byte literal
+        if ((i64)ip < win || (i64)ip + 136 > win + kInWin) {
             win = (i64)ip - (i64)((src_a + ip) & 15);                    // 16-byte aligned global loads
             wave_sync();
             for (int o = lane * 16; o < kInWin; o += 64 * 16)
                 *(uint4*)(inb + o) = *(const uint4*)(src + win + o);     // reads past n_in stay inside the padded stage
             wave_sync();
-            whave = false;
         }
-        if (!whave || ip + 5 > wpos + 64) { wbyte = inb[(i64)ip - win + lane]; wpos = ip; whave = true; }
-        const int r = (int)(ip - wpos);
-        const u32 tag = (u32)__builtin_amdgcn_readlane((int)wbyte, r), b1 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 1),
-                  b2 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 2), b3 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 3),
-                  b4 = (u32)__builtin_amdgcn_readlane((int)wbyte, r + 4);
-        if ((tag & 3) == 0) {                                            // literal
-            u32 len = tag >> 2, hdr = 1;
-            if (len >= 60) {
-                const u32 nb = len - 59; hdr += nb;
-                const u32 v = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
-                len = nb == 4 ? v : (v & ((1u << (8 * nb)) - 1));
+        // 1. the element that would start at byte ip + lane
+        const unsigned char* q = inb + ((i64)ip - win) + lane;
+        const u32 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3], c4 = q[4];
+        const u32 type = c0 & 3;
+        u32 hdr, olen, off = 0;
+        if (type == 0) {
+            const u32 L = c0 >> 2;
+            if (L < 60) { hdr = 1; olen = L + 1; }
+            else {
+                const u32 nb = L - 59;
+                u32 v = c1 | (c2 << 8) | (c3 << 16) | (c4 << 24);
+                if (nb < 4) v &= (1u << (8 * nb)) - 1;
+                hdr = 1 + nb; olen = v >= 0x7FFFFFF0u ? 0x7FFFFFF0u : v + 1;
             }
-            len += 1; ip += hdr;
+        } else if (type == 1) { hdr = 2; olen = 4 + ((c0 >> 2) & 7); off = ((c0 >> 5) << 8) | c1; }
+        else if (type == 2) { hdr = 3; olen = (c0 >> 2) + 1; off = c1 | (c2 << 8); }
+        else { hdr = 5; olen = (c0 >> 2) + 1; off = c1 | (c2 << 8) | (c3 << 16) | (c4 << 24); }
+        const u32 ilen = type == 0 ? hdr + olen : hdr;                   // input bytes of the element
+        // 2. walk the chain of real element starts inside the window
+        u64 starts = 0; u32 pos = 0;
+        const u32 avail = min(64u, n_in - ip);
+        while (pos < avail) {
+            const u32 il = rl(ilen, pos);
+            if (pos + il > 64) break;                                    // a literal that leaves the window goes alone
+            starts |= 1ull << pos; pos += il;
+        }
+        if (starts == 0) {                                               // lone literal at ip
+            const u32 len = rl(olen, 0);
+            ip += rl(hdr, 0);
             if (ip > n_in || len > n_in - ip || len > n_out - op) { bad = true; break; }
-            if (len <= 64) {                                             // short literal: LDS window -> ring
-                commit();
-                if (lane < (int)len) pval = inb[(i64)ip - win + lane];
-                ppos = op; plen = len;
-            } else {                                                     // long literal: input -> global + ring
-                commit();
+            if (len <= 64) {                                             // LDS window -> ring
+                if (lane < (int)len) ring[(op + lane) & RM] = inb[(i64)ip - win + lane];
+            } else {                                                     // input -> global + ring
                 flush(op);
                 const unsigned char* s = src + ip;
                 const u32 h = min(len, (16u - (op & 15)) & 15);
@@ -419,30 +429,53 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
                 flushed = op + len;
             }
             ip += len; op += len;
-        } else {                                                         // copy
-            u32 len, off;
-            if ((tag & 3) == 1) { len = 4 + ((tag >> 2) & 7); off = ((tag >> 5) << 8) | b1; ip += 2; }
-            else if ((tag & 3) == 2) { len = (tag >> 2) + 1; off = b1 | (b2 << 8); ip += 3; }
-            else { len = (tag >> 2) + 1; off = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); ip += 5; }
-            if (off == 0 || off > op || len > n_out - op || ip > n_in) { bad = true; break; }
-            const u32 k = (off >= len) ? (u32)lane : (u32)lane % off;    // overlapping copies repeat the last `off` bytes
-            commit();
+        } else {
+            const bool isstart = (starts >> lane) & 1;
+            // output position of every element: exclusive scan of the output lengths over the start lanes
+            u32 incl = isstart ? olen : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)incl, o, kWave); if (lane >= o) incl += t; }
+            const u32 total = rl(incl, 63);
+            const u32 opos = op + incl - (isstart ? olen : 0);
+            // validation of the whole batch (in-window elements are small: no overflow in these sums)
+            const bool lb = isstart && (opos + olen > n_out || ip + lane + ilen > n_in ||
+                                        (type != 0 && (off == 0 || off > opos)));
+            if (__ballot(lb)) { bad = true; break; }
+            // 3. literal bodies: lane l belongs to the last start s <= l; it is payload if l >= s + hdr_s
+            const u64 below = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+            const int s_l = 63 - __clzll((long long)below);              // starts has bit 0 set
+            const u32 s_type = (u32)__shfl((int)type, s_l, kWave), s_hdr = (u32)__shfl((int)hdr, s_l, kWave),
+                      s_opos = (u32)__shfl((int)opos, s_l, kWave);
+            if ((u32)lane < pos && s_type == 0 && (u32)lane >= (u32)s_l + s_hdr)
+                ring[(s_opos + (u32)lane - (u32)s_l - s_hdr) & RM] = (unsigned char)c0;
             wave_sync();
-            if (off <= kRing) {
-                if (lane < (int)len) pval = ring[(op - off + k) & RM];
-            } else {                                                     // beyond the ring: read the output back
-                flush(op);
-                __threadfence_block();
-                __syncthreads();
-                if (lane < (int)len) pval = ((volatile unsigned char*)dst)[op - off + k];
+            // 4. copies, in stream order
+            u64 cm = __ballot(isstart && type != 0);
+            while (cm) {
+                const u32 s_c = (u32)__builtin_ctzll(cm);
+                cm &= cm - 1;
+                const u32 len = rl(olen, s_c), of = rl(off, s_c), o = rl(opos, s_c);
+                u32 k = (u32)lane;
+                if (of < len) k = (u32)lane % of;                        // overlapping copies repeat the last `of` bytes (scalar branch)
+                unsigned char b = 0;
+                if (of <= (u32)(kRing - kBatchOut)) {                     // the ring still holds the source
+                    if (lane < (int)len) b = ring[(o - of + k) & RM];
+                } else {                                                 // beyond the ring: read the output back
+                    flush(o);
+                    __threadfence_block();
+                    __syncthreads();
+                    if (lane < (int)len) b = ((volatile unsigned char*)dst)[o - of + k];
+                }
+                wave_sync();
+                if (lane < (int)len) ring[(o + lane) & RM] = b;
+                wave_sync();
             }
-            ppos = op; plen = len;
-            op += len;
+            op += total; ip += pos;
         }
-        if ((op ^ flushed) >= (u32)kFlush) { commit(); flush(op & ~(u32)(kFlush - 1)); }   // crossed an 8 KB boundary
+        if ((op ^ flushed) >= (u32)kFlush) flush(op & ~(u32)(kFlush - 1));   // crossed an 8 KB boundary
         wave_sync();
     }
-    if (!bad) { commit(); flush(op); }
+    if (!bad) flush(op);
     if (bad || op != n_out) { if (lane == 0) pq_error(err, PQE_SNAPPY, pi); }
 }
 

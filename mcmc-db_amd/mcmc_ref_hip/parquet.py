@@ -191,7 +191,7 @@ def read_draws_many(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Ite
             want = list(params[k]) if params is not None and params[k] is not None else \
                 [n for n, t in zip(f.column_names, f.column_types) if n not in ("chain", "draw") and t in NUMERIC]
             wants.append(want)
-            sizes.append((-(-len(want) * f.num_rows * 8 // 256)) * 256)       # 256-byte aligned slices
+            sizes.append(len(want) * f.num_rows * 8)       # packed: same-shape neighbours form ONE [P][C][N] tensor
         arena = _Arena(ctx, sum(sizes))
         id_rows = sum(f.num_rows for f in files)
         ids_all = DeviceBuffer(ctx, max(2 * id_rows * 8, 8))
@@ -287,40 +287,56 @@ def summarize_files(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Ite
     qs = list(quantiles)
     models = read_draws_many(ctx, sources, params)
     try:
-        pending = []
-        for d in models:
+        # Jobs: maximal runs of neighbouring models that sit back to back in the arena and share (C, N) are ONE
+        # tensor with their parameters concatenated -- one kernel pipeline instead of one per model.
+        jobs = []                                    # (first model, n models, tensor args, min_chains, diagnostics)
+        for k, d in enumerate(models):
             P, M = len(d.params), int(d.counts.sum())
             if P == 0:
-                pending.append(None)
                 continue
-            if diagnostics:
-                if len(d.counts) < min_chains:
-                    raise ValueError(f"R-hat diagnostics require at least {min_chains} chains; got {len(d.counts)} chain(s)")
-                if d.tensor is None:                 # ragged chains: pooled stats now, one pipeline per parameter below
-                    t = DeviceTensor(ctx, d.buf, (MCR_F64, 1, M, P, M, 1, M))
-                    if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
-                        ctx.wait_one()
-                    pending.append(ctx.enqueue(t, min_chains=1, quantiles=qs, diagnostics=False))
+            if diagnostics and len(d.counts) < min_chains:
+                raise ValueError(f"R-hat diagnostics require at least {min_chains} chains; got {len(d.counts)} chain(s)")
+            if not diagnostics and M == 0:
+                raise ValueError("cannot compute stats of empty columns")
+            full = diagnostics and d.tensor is not None      # ragged chains: pooled stats here, diagnostics below
+            shape = (len(d.counts), int(d.counts[0])) if full else (1, M)
+            if jobs and M > 0:
+                j = jobs[-1]
+                last = models[j["first"] + j["count"] - 1]
+                if (k == j["first"] + j["count"] and j["shape"] == shape and j["full"] == full
+                        and isinstance(d.buf, _View) and isinstance(last.buf, _View)
+                        and last.buf.ptr.value + len(last.params) * M * 8 == d.buf.ptr.value):
+                    j["count"] += 1
+                    j["P"] += P
                     continue
-                t = d.tensor
-            else:
-                if M == 0:
-                    raise ValueError("cannot compute stats of empty columns")
-                t = DeviceTensor(ctx, d.buf, (MCR_F64, 1, M, P, M, 1, M))
+            jobs.append({"first": k, "count": 1, "shape": shape, "full": full, "P": P, "buf": d.buf})
+        pending = []
+        for j in jobs:
+            Cn, N = j["shape"]
+            t = DeviceTensor(ctx, j["buf"], (MCR_F64, Cn, N, j["P"], N, 1, Cn * N))
             if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
                 ctx.wait_one()
             try:
-                pending.append(ctx.enqueue(t, min_chains=min_chains if diagnostics else 1, quantiles=qs,
-                                           diagnostics=diagnostics))
+                pending.append(ctx.enqueue(t, min_chains=min_chains if j["full"] else 1, quantiles=qs,
+                                           diagnostics=j["full"]))
             except McrError as exc:
                 raise ValueError(exc.message) from exc
         try:
             ctx.wait()
         except McrError as exc:
             raise ValueError(exc.message) from exc
+        results = [None] * len(models)
+        for j, b in zip(jobs, pending):
+            r = b.result()
+            p0 = 0
+            for k in range(j["first"], j["first"] + j["count"]):
+                P = len(models[k].params)
+                if P == 0:
+                    continue
+                results[k] = {key: (v[p0:p0 + P] if key != "q_lo" else v) for key, v in r.items()}
+                p0 += P
         out = []
-        for d, b in zip(models, pending):
-            r = b.result() if b is not None else None
+        for d, r in zip(models, results):
             if r is not None and diagnostics and d.tensor is None:
                 x = d.to_host()
                 off = np.concatenate([[0], np.cumsum(d.counts)])

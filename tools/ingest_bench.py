@@ -95,10 +95,6 @@ def main():
         ctx.profile(False)
         for d in ds:
             d.free()
-        t0 = time.perf_counter()
-        for p in paths:
-            parquet.ParquetFile(p).close()
-        t_parse = time.perf_counter() - t0
         for f in files:
             f.close()
     best_a = min(ta)
@@ -108,7 +104,7 @@ def main():
         "identical_statistics": bool(same),
         "arrow_route_s": best_a[0], "arrow_decode_s": best_a[1], "arrow_upload_summarise_s": best_a[2],
         "native_route_s": min(tn),
-        "native_decode_only_s": t_decode, "native_metadata_parse_s": t_parse,
+        "native_decode_only_s": t_decode,
         "speedup_end_to_end": best_a[0] / min(tn),
         "param_draws_per_s_native": total_pd / min(tn), "param_draws_per_s_arrow": total_pd / best_a[0],
         "decode_kernels_ms": {k: v["total_ms"] for k, v in prof.items() if k.startswith("k_pq") or k == "k_gather_rows"},
