@@ -365,3 +365,53 @@ def test_inflight_limit_and_context_reuse(ctx, oracle):
         check_summary(ctx.summarize(t), exp, what="reuse-dev")
     finally:
         t.free()
+
+
+def _bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.dtype == np.float64:
+        return np.array_equal(a.view(np.int64), b.view(np.int64))
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape,dtype", [((4, 10000, 100), np.float64),      # BASELINE config 1, full size
+                                         ((4, 100000, 24), np.float32)])     # config 4 geometry (N = 100000), P slice
+def test_full_size_properties(ctx, shape, dtype):
+    """Size-independent properties at the sizes the oracle is too slow for:
+      * scaling the draws by 2 is exact in floating point and keeps every order, so the rank-based diagnostics
+        (rhat*, ess*, truncation lags) must come back BIT-identical and mean / std / quantiles exactly doubled;
+      * parameters are independent: permuting them permutes the results bit for bit (what sharding relies on);
+      * a chunked workspace gives the same bits as one pass; ESS <= C*N; quantiles are ordered;
+      * the moments agree with the generator (iid N(p, sigma_p), sigma_p = 10^((p mod 7) - 3))."""
+    C_, N, P = shape
+    t = ctx.alloc_tensor(C_, N, P, dtype)
+    ctx.fill_synthetic(t, 4711)
+    host = t.buf.download(dtype, C_ * N * P).reshape(P, C_, N)
+    base = ctx.summarize(t)
+    M = C_ * N
+    sig = 10.0 ** ((np.arange(P) % 7) - 3)
+    assert np.all(np.abs(base["mean"] - np.arange(P)) < 6 * sig / np.sqrt(M))
+    assert np.all(np.abs(base["std"] / sig - 1) < 0.02)
+    assert np.all(base["ess_bulk"] <= M) and np.all(base["ess_tail"] <= M) and np.all(base["ess_bulk"] > 0.5 * M)
+    assert np.all(np.abs(base["rhat"] - 1) < 0.01)
+    assert np.all(np.diff(base["q"], axis=1) > 0) and _bits_equal(base["q"][:, 1], base["median"])
+    # x -> 2x
+    dbl = ctx.summarize(host * dtype(2), "pcn")
+    for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
+        assert _bits_equal(dbl[k], base[k]), k
+    for k in ("mean", "std", "q", "median"):
+        assert _bits_equal(dbl[k], 2 * base[k]), k
+    # parameter permutation (and the host-upload path against the device-resident one)
+    perm = np.random.default_rng(0).permutation(P)
+    pr = ctx.summarize(np.ascontiguousarray(host[perm]), "pcn")
+    for k in ("mean", "std", "q", "median", "rhat", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
+        assert _bits_equal(pr[k], base[k][perm]), k
+    # chunked workspace
+    ctx._check(ctx.lib.mcr_set_workspace_limit(ctx.handle, 96 << 20))
+    try:
+        ch = ctx.summarize(t)
+    finally:
+        ctx._check(ctx.lib.mcr_set_workspace_limit(ctx.handle, 8 << 30))
+    for k in ("mean", "std", "q", "rhat", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
+        assert _bits_equal(ch[k], base[k]), k
+    t.free()
