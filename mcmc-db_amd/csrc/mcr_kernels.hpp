@@ -230,7 +230,8 @@ __global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, c
     const double m = (double)M;
     const double mu = s1 / m;
     double var = (s2 - s1 * mu) / m;
-    if (var < 0.0) var = 0.0;
+    if (isinf(s2)) var = INFINITY;          // squares overflowed: inf like np.std, not inf - inf
+    else if (!(var >= 0.0)) var = 0.0;
     mean[p] = K + mu;
     stdv[p] = sqrt(var);
     if (bad) bad[p] = b;
@@ -930,7 +931,8 @@ __global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const 
     }
     const double K = X[p * M], m = (double)M, mu = s1 / m;
     double var = (s2 - s1 * mu) / m;
-    if (var < 0.0) var = 0.0;
+    if (isinf(s2)) var = INFINITY;          // squares overflowed: inf like np.std, not inf - inf
+    else if (!(var >= 0.0)) var = 0.0;
     res[R_MEAN * P + p] = K + mu;
     res[R_STD * P + p] = sqrt(var);
     res[R_BAD * P + p] = b;

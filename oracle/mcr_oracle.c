@@ -107,6 +107,7 @@ static double comp_sum(const double* v, int64_t n, double shift, int sq)
         if (fabs(s) >= fabs(x)) c += (s - t) + x; else c += (x - t) + s;
         s = t;
     }
+    if (isinf(s)) return s;   /* overflow: the plain sum numpy / pyarrow return (the correction term is inf - inf) */
     return s + c;
 }
 /* diagnostics.py:196-201 _variance (ddof=1; n<2 -> 0.0) */

@@ -415,3 +415,27 @@ def test_full_size_properties(ctx, shape, dtype):
     for k in ("mean", "std", "q", "rhat", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
         assert _bits_equal(ch[k], base[k]), k
     t.free()
+
+
+def test_extreme_shapes_and_scales(ctx, oracle):
+    """Grid and value-range extremes: more parameters than one grid dimension holds, the chain-count limit, one
+    long pooled array with heavy ties, slow-mixing random walks (truncation lag in the thousands: the direct
+    continuation loop), denormal- and overflow-scale draws (std overflows to inf exactly like np.std)."""
+    rng = np.random.default_rng(0)
+    cases = {
+        "P=70000": rng.normal(size=(70000, 2, 8)),
+        "C=256": rng.normal(size=(3, 256, 40)),
+        "C=1": rng.normal(size=(2, 1, 5000)),
+        "ties-1.2M": np.round(rng.normal(size=(1, 4, 300000)), 2),
+        "random-walk": np.cumsum(rng.normal(size=(2, 4, 20000)), axis=2),
+        "denormal": rng.normal(size=(4, 4, 4096)) * 1e-300,
+        "overflow": rng.normal(size=(4, 4, 4096)) * 1e300,
+    }
+    for what, x in cases.items():
+        got = ctx.summarize(x, "pcn", min_chains=1)
+        exp = oracle.summarize(x, "pcn", min_chains=1)
+        if what == "overflow":
+            assert np.all(np.isinf(got["std"])) and np.all(np.isinf(exp["std"]))
+            got["std"][:] = exp["std"][:] = 1e300          # check_summary scales the mean tolerance by std
+        check_summary(got, exp, what=what)
+    assert cases["random-walk"].shape and int(ctx.summarize(cases["random-walk"], "pcn")["lag_bulk"].min()) > 1000
