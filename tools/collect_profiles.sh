@@ -24,4 +24,4 @@ find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_fe
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python3 $SHORT > /dev/null 2> /tmp/prof_w.err
 find /tmp/prof_w -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_write_c1.csv" \;
 cd "$REPO" && python tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch_c1.csv" "$OUT/${TAG}_pmc_write_c1.csv" > "$OUT/pmc_traffic.json"
-tail -3 /tmp/prof_kt.err /tmp/prof_f.err; ls -la "$OUT"
+ls -la "$OUT"
