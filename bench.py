@@ -314,6 +314,19 @@ def main():
                    "sample": f"the same {C}x{N}x{P} {a.dtype} model, {passes} passes of oracle/mcr_oracle.c with its "
                              f"parameters split over {T} threads ({total_s:.1f} s; {os.cpu_count()} cores visible)",
                    "value_1core": C * N * P / cpu_s}
+            if a.layout == "pcn" and a.dtype == "f64" and C >= 2:
+                # the "NumPy CPU path" of SURVEY 8(d): the same statistics vectorised with numpy / scipy
+                # (argsort ranks, ndtri, FFT autocovariances), same thread split, ~6 s sample
+                from oracle import numpy_path
+                npass, nsec = 0, 0.0
+                with ThreadPoolExecutor(T) as pool:
+                    while nsec < 6.0 and npass < 32:
+                        t1 = time.perf_counter()
+                        list(pool.map(numpy_path.summarize, parts))
+                        nsec += time.perf_counter() - t1
+                        npass += 1
+                cpu["numpy_path"] = {"value": npass * C * N * P / nsec, "unit": "param-draws/s", "cores": T,
+                                     "sample": f"{npass} passes of oracle/numpy_path.py over {T} threads ({nsec:.1f} s)"}
     if dist is not None:
         flag = torch.tensor([1.0 if (valid and gathered_ok) else 0.0], device=dist_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)

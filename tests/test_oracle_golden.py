@@ -157,3 +157,19 @@ def test_compare_and_basic_cases(oracle):
     st = oracle.stats([float(i) * 0.1 for i in range(100)])
     for b in ("arrow", "numpy"):
         assert rel_close(st["mean"], bc[b]["mu"]["mean"], 1e-10) and rel_close(st["std"], bc[b]["mu"]["std"], 1e-10)
+
+
+def test_numpy_path_agrees_with_the_c_oracle(oracle):
+    """oracle/numpy_path.py (the "NumPy CPU path" timed by bench.py) against the C restatement: integers exact,
+    floats to 1e-9 (ndtri / FFT differ from AS241 / direct sums in the last bits)."""
+    from oracle import numpy_path
+    rng = np.random.default_rng(3)
+    cases = [rng.normal(size=(3, 4, 500)), np.round(rng.normal(size=(2, 4, 301)), 1),
+             np.cumsum(rng.normal(size=(2, 3, 400)), axis=2) * 0.05 + rng.normal(size=(2, 3, 400)),
+             np.stack([np.full((4, 50), 2.5), rng.normal(size=(4, 50))])]
+    for x in cases:
+        a, b = numpy_path.summarize(x), oracle.summarize(x, "pcn", min_chains=1)
+        assert np.array_equal(a["lag_bulk"], b["lag_bulk"]) and np.array_equal(a["lag_tail"], b["lag_tail"])
+        assert np.array_equal(a["q"], b["q"]) and np.array_equal(a["median"], b["median"])
+        for k in ("mean", "std", "rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
+            assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12, equal_nan=True), k
