@@ -189,6 +189,7 @@ inline bool parse_page_header(File& f, u64 off, Page& pg)
         } else t.skip(ft);
     }
     if (!t.ok || type < 0 || usz < 0 || csz < 0) return fail(f, "truncated or malformed page header");
+    if (usz > (i64)(1u << 30) || csz > (i64)(1u << 30)) return fail(f, "page larger than 1 GiB");
     pg.kind = (int)type; pg.uncomp_size = (u32)usz; pg.comp_size = (u32)csz;
     pg.payload_off = off + (u64)(t.p - (f.bytes + off));
     if (pg.payload_off + pg.comp_size > f.len) return fail(f, "page payload beyond the end of the file");

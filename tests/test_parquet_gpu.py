@@ -245,3 +245,33 @@ def test_reference_api_native_reader_equals_arrow_reader(ctx, tmp_path, monkeypa
                 assert both[name][p][k] == pytest.approx(rec["meta_diagnostics"][p][k], rel=1e-6)
     with pytest.raises(KeyError):
         reference.stats("radon_pooled", params=["nope"], store=st)
+
+
+def test_corrupted_files_fail_cleanly_or_decode_in_bounds(ctx):
+    """Random byte damage anywhere in a file (headers, Snappy streams, run headers, dictionary indices): the call
+    either reports an error or returns arrays of the right shape -- never a crash, a hang or an out-of-bounds
+    access (every device-side read and write is bounded by sizes the host validated)."""
+    from mcmc_ref_hip._ffi import McrError
+    from mcmc_ref_hip.parquet import read_columns
+    rng = np.random.default_rng(99)
+    n = 4000
+    t = pa.table({"chain": np.repeat(np.arange(4), n // 4), "draw": np.tile(np.arange(n // 4), 4),
+                  "x": rng.normal(size=n), "ties": np.round(rng.normal(size=n), 1),
+                  "ramp": np.arange(n, dtype=np.float64)})
+    outcomes = {"ok": 0, "error": 0}
+    for kw in (dict(), dict(use_dictionary=False), dict(compression="none"), dict(data_page_version="2.0")):
+        img = image(t, **kw)
+        flen = int.from_bytes(img[-8:-4], "little")
+        body = len(img) - 8 - flen
+        for _ in range(60):
+            b = bytearray(img)
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(4, body))] = int(rng.integers(0, 256))      # page headers and payloads
+            try:
+                got = read_columns(ctx, bytes(b))
+                assert all(v.shape == (n,) for v in got.values())
+                outcomes["ok"] += 1
+            except McrError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["ok"] > 0, outcomes
+    check_roundtrip(ctx, image(t))                             # the context is still healthy
