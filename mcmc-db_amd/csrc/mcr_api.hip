@@ -332,10 +332,10 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
                (const unsigned*)a.more, a.rec2);
     }
-    LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(256), (size_t)2 * a.C * 8, (const u32*)a.zb,
+    LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, (const double*)a.state,
-           (const double*)a.chstate, a.d_res, a.pc);
+           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB);   // kA / kB: the sort's key buffers, free by now
     return MCR_OK;
 }
 

@@ -365,22 +365,24 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
 
 // Continuation for flagged pairs: lags 64..255 from the second k_acov_seg pass, then (very sticky
 // chains only) a direct deviation-product loop over L2 from lag 256.  grid (P, 2), block 256.
-__global__ __launch_bounds__(256) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
+__global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                                        const double* __restrict__ ztab, i64 M,
                                                        const i64* __restrict__ off, int C, i64 n, int nseg,
                                                        const double* __restrict__ rec2,
                                                        const unsigned* __restrict__ more,
                                                        const double* __restrict__ state,
                                                        const double* __restrict__ chstate,
-                                                       double* __restrict__ res, i64 P)
+                                                       double* __restrict__ res, i64 P,
+                                                       double* __restrict__ dev_b, double* __restrict__ dev_t)
 {
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
     if (more[pk] == 0u) return;
     __shared__ double tot[64];
-    __shared__ double wred[4 * 64];
+    __shared__ double wred[16 * 64];
     __shared__ double ctl[2];
+    const int nwv = (int)(blockDim.x >> 6);             // 16 waves: the direct loop below is latency-bound
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u32* z = (kind ? zt : zb) + p * M;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void k_diag_combine2(const u32* __restrict__ z
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     double* hb = reinterpret_cast<double*>(smem2);
     double* tb = hb + C;
-    for (int c = tid; c < C; c += 256) { hb[c] = chstate[(pk * C + c) * kChState + 3]; tb[c] = chstate[(pk * C + c) * kChState + 4]; }
+    for (int c = tid; c < C; c += (int)blockDim.x) { hb[c] = chstate[(pk * C + c) * kChState + 3]; tb[c] = chstate[(pk * C + c) * kChState + 4]; }
     __syncthreads();
     for (int blk = 0; blk < kMoreBlocks && !stop; ++blk) {
         const i64 lb = 64 + 64 * blk;
@@ -433,21 +435,43 @@ __global__ __launch_bounds__(256) void k_diag_combine2(const u32* __restrict__ z
         stop = ctl[0] != 0.0;
         __syncthreads();
     }
-    // ---- beyond lag 255: direct products of deviations, 64 lags per round, 4 waves over i ----
-    for (i64 lb = 64 + 64 * kMoreBlocks; lb < n && !stop; lb += 64) {
-        const i64 lag = lb + lane;
-        double acc = 0.0;
+    // ---- beyond lag 255: direct products of deviations, 64 lags per round (lane = lag), the waves split i.
+    //      The deviations z - mean are materialised once in scratch ([M] doubles per pair: the sort's key buffers,
+    //      free by now), so the loop reads coalesced doubles instead of gathering the z table per product. ----
+    double* dev = (kind ? dev_t : dev_b) + p * M;
+    if (64 + 64 * kMoreBlocks < n && !stop) {
         for (int c = 0; c < C; ++c) {
             const double* cs = chstate + (pk * C + c) * kChState;
-            if (cs[2] != 0.0) continue;
+            const bool konst = cs[2] != 0.0;
             const double m = cs[0];
             const u32* zc = z + off[c];
-            for (i64 i = w; i + lag < n; i += 4) acc = fma(zdec(ztab, zc[i], M) - m, zdec(ztab, zc[i + lag], M) - m, acc);
+            double* dc = dev + off[c];
+            for (i64 i = tid; i < n; i += blockDim.x) dc[i] = konst ? 0.0 : zdec(ztab, zc[i], M) - m;
         }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (i64 lb = 64 + 64 * kMoreBlocks; lb < n && !stop; lb += 64) {
+        const i64 lag = lb + lane;
+        double acc = 0.0, acc2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double* dc = dev + off[c];
+            i64 i = (i64)w * 8;
+            for (; i + 7 + lag < n; i += 8 * nwv) {
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = dc[i + u]; b[u] = dc[i + u + lag]; }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { acc = fma(a[u], b[u], acc); acc2 = fma(a[u + 1], b[u + 1], acc2); }
+            }
+            for (int u = 0; u < 8; ++u)
+                if (i + u + lag < n) acc = fma(dc[i + u], dc[i + u + lag], acc);
+        }
+        acc += acc2;
         __syncthreads();
         wred[w * 64 + lane] = acc;
         __syncthreads();
-        if (tid < 64) tot[tid] = wred[tid] + wred[64 + tid] + wred[128 + tid] + wred[192 + tid];
+        if (tid < 64) { double t = 0.0; for (int ww = 0; ww < nwv; ++ww) t += wred[ww * 64 + tid]; tot[tid] = t; }
         __syncthreads();
         if (tid == 0) {
             double st = 0.0;
