@@ -91,8 +91,13 @@ typedef struct mcr_kernel_time {
 /* ---- lifecycle -------------------------------------------------------------------- */
 int mcr_version(void);
 int mcr_device_count(void);
-/* Creates a context bound to HIP device `device` (own non-blocking stream, lazily grown
- * workspace).  Fails with MCR_ENODEVICE when no GPU is present: there is no CPU fallback. */
+/* Creates a context bound to HIP device `device` (own non-blocking streams, lazily grown
+ * workspaces).  Fails with MCR_ENODEVICE when no GPU is present: there is no CPU fallback.
+ * Environment read here: MCR_LANES (streams + workspaces that consecutive calls rotate over,
+ * default 4, max MCR_MAX_INFLIGHT), MCR_GRAPH=0 (no hipGraph capture / replay of the launch
+ * sequence), MCR_WORKSPACE_MB (see mcr_set_workspace_limit).
+ * Limits: C <= 256 chains, C * N < 2^31 pooled draws per parameter (rank codes are 32-bit),
+ * any number of parameters (chunked through the workspace). */
 int mcr_init(int device, mcr_ctx** out);
 void mcr_free(mcr_ctx* ctx);
 const char* mcr_last_error(const mcr_ctx* ctx); /* ctx may be NULL: last mcr_init failure */
