@@ -81,6 +81,7 @@ struct mcr_ctx {
     size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
     int lane = 0, n_lanes = 4;
     void* stage = nullptr; size_t stage_bytes = 0;  // device copy of host tensors (mcr_summarize)
+    hipStream_t copy_stream = nullptr;              // uploads of mcr_summarize, overlapped with the lanes' kernels
     // Parquet ingest (mcr_parquet_decode): uploaded column chunks, decompression scratch, page table + error word
     void* pq_stage = nullptr; size_t pq_stage_bytes = 0;
     void* pq_scratch = nullptr; size_t pq_scratch_bytes = 0;
@@ -762,7 +763,9 @@ int mcr_init(int device, mcr_ctx** out)
     e = hipSetDevice(device);
     for (int l = 0; l < ctx->n_lanes && e == hipSuccess; ++l)
         e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
+        if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
         for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
         delete ctx;
         return fail(nullptr, MCR_EHIP, "device %d init failed: %s", device, hipGetErrorString(e));
@@ -799,6 +802,7 @@ void mcr_free(mcr_ctx* ctx)
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
     if (ctx->pq_tab) hipFree(ctx->pq_tab);
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -914,6 +918,38 @@ int mcr_summarize(mcr_ctx* ctx, const void* draws, int dtype, int64_t C, int64_t
     if (ext > 0) {
         rc = ensure_stage(ctx, (size_t)ext * es);
         if (rc) return rc;
+    }
+    // Parameter-major tensors (the Arrow column layout) of some size go up in a few pieces: while piece k + 1
+    // crosses PCIe on the copy stream, the kernels of piece k already run on a lane (pageable host memory makes
+    // the copy itself synchronous for the host, which has nothing better to do).
+    const i64 per_param = tensor_extent(C, N, 1, sc, sn, 0);
+    const bool separable = P >= 2 && C * N > 0 && sp >= per_param && ctx->n_inflight == 0 && ctx->n_lanes > 1;
+    if (separable && (size_t)ext * es >= ((size_t)8 << 20)) {
+        int pieces = ctx->n_lanes < 4 ? ctx->n_lanes : 4;
+        if ((i64)pieces > P) pieces = (int)P;
+        const int nqq = n_q > 0 ? n_q : 0;
+        for (int k = 0; k < pieces && !rc; ++k) {
+            const i64 p0 = P * k / pieces, p1 = P * (k + 1) / pieces, pc = p1 - p0;
+            const size_t b0 = (size_t)p0 * (size_t)sp * es;
+            const size_t bytes = (size_t)tensor_extent(C, N, pc, sc, sn, sp) * es;
+            hipError_t e = hipMemcpyAsync((char*)ctx->stage + b0, (const char*)draws + b0, bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+            if (e != hipSuccess) { rc = fail(ctx, MCR_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
+            mcr_summary o = *out;
+            auto adv = [&](double*& q, i64 n) { if (q) q += n; };
+            adv(o.mean, p0); adv(o.std, p0); adv(o.q, p0 * nqq); adv(o.median, p0); adv(o.rhat, p0); adv(o.rhat_bulk, p0);
+            adv(o.rhat_tail, p0); adv(o.ess_bulk, p0); adv(o.ess_tail, p0);
+            if (o.lag_bulk) o.lag_bulk += p0;
+            if (o.lag_tail) o.lag_tail += p0;
+            rc = mcr_summarize_enqueue(ctx, (const char*)ctx->stage + b0, dtype, C, N, pc, sc, sn, sp, min_chains, quantiles, n_q, &o);
+        }
+        char keep[512];
+        memcpy(keep, ctx->err, sizeof keep);
+        const int rw = wait_impl(ctx);
+        if (rc) { memcpy(ctx->err, keep, sizeof keep); return rc; }
+        return rw;
+    }
+    if (ext > 0) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->stage, draws, (size_t)ext * es, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pipeline may run on the other lane
     }

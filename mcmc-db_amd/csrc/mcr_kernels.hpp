@@ -594,7 +594,8 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
             i64 gs = d0 + rs[i], ge = d0 + re[i];
             if (ext0 && v == vfirst) gs = gfirst;
             if (ext1 && v == vlast) ge = glast;
-            z[p * M + sidx[pos16(e)]] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
+            const u32 t_idx = min(sidx[pos16(e)], (u32)(M - 1));     // stale order after a rejected (NaN) partition
+            z[p * M + t_idx] = (u32)(gs + ge);            // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
     const i64 p = blockIdx.x;
     const double* kp = keys + p * M;
     for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; srank[i] = i % SPT; }
+    for (int b = tid; b <= B; b += NTS) splt[b] = -1;      // -1 = splitter b not found (only with NaN / Inf draws)
     __syncthreads();
     // pooled rank of every finite sample = own index + samples of every other run below it;
     // one (sample, other run) pair per thread step
@@ -655,6 +657,17 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
         }
     }
     __syncthreads();
+    // Non-finite draws (the call will be rejected with MCR_ENONFINITE) break the ordering the splitters rely on:
+    // leave an EMPTY partition behind, so that no later kernel walks cut tables made of garbage.
+    {
+        int missing = 0;
+        for (int b = 1 + tid; b < B; b += NTS) missing |= (splt[b] < 0);
+        if (__syncthreads_or(missing)) {
+            for (int q = tid; q < (B + 1) * k; q += NTS) cut[p * (i64)(B + 1) * k + q] = 0u;
+            for (int b = tid; b <= B; b += NTS) boff[p * (B + 1) + b] = 0u;
+            return;
+        }
+    }
     // cuts: position in run t where bucket b starts
     for (int q = tid; q < (B + 1) * k; q += NTS) {
         const int b = q / k, t = q % k;
@@ -753,6 +766,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     const int padded = sst[k];          // <= 4096 by construction of D
     const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
     const i64 obase = boff[p * (B + 1) + b];
+    if (padded > T || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
     // gather pieces (+inf pads)
     for (int e = tid; e < padded; e += NT) {
         int t = 0;   // last piece whose padded start is <= e (starts are non-decreasing)
@@ -840,7 +854,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             i64 gs = obase + rs[i], ge = obase + re[i];
             if (ext0 && v == vfirst) gs = sedge[0];
             if (ext1 && v == vlast) ge = sedge[3];
-            z[p * M + sidx[pos16(e)]] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
+            z[p * M + min(sidx[pos16(e)], (u32)(M - 1))] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
@@ -911,7 +925,7 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
         }
         e = lo + 1;
     }
-    z[p * M + idx[p * M + i]] = (u32)(s + e);   // code of the tie run: rank = (code + 1) / 2
+    z[p * M + min(idx[p * M + i], (u32)(M - 1))] = (u32)(s + e);   // code of the tie run: rank = (code + 1) / 2
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -439,3 +439,40 @@ def test_extreme_shapes_and_scales(ctx, oracle):
             got["std"][:] = exp["std"][:] = 1e300          # check_summary scales the mean tolerance by std
         check_summary(got, exp, what=what)
     assert cases["random-walk"].shape and int(ctx.summarize(cases["random-walk"], "pcn")["lag_bulk"].min()) > 1000
+
+
+def test_host_upload_in_pieces(ctx, oracle):
+    """Host tensors of >= 8 MB in parameter-major layout are uploaded in pieces that overlap the kernels of the
+    previous piece: same bits as the device-resident path, errors still reported, strided layouts untouched."""
+    from mcmc_ref_hip._ffi import McrError, MCR_ENONFINITE
+    from mcmc_ref_hip import synth
+    x = synth.c1_model(4, 10000, 37, seed=5)                         # 11.8 MB: 4 pieces of 9-10 parameters
+    got = ctx.summarize(x, "pcn")
+    t = ctx.upload(x, "pcn")
+    dev = ctx.summarize(t)
+    t.free()
+    for k in ("mean", "std", "q", "median", "rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail", "q_lo"):
+        assert _bits_equal(got[k], dev[k]), k
+    check_summary({k: v[:3] for k, v in got.items() if k != "q_lo"},
+                  oracle.summarize(x[:3], "pcn"), what="pieces")
+    st = ctx.summarize(x, "pcn", diagnostics=False, quantiles=(0.1, 0.9))
+    assert _bits_equal(st["mean"], dev["mean"]) and np.isnan(st["rhat"]).all() and st["q"].shape == (37, 2)
+    for poison in (np.nan, np.inf, -np.inf):                         # non-finite draws in a multi-tile parameter:
+        bad = x.copy()                                               # rejected, and no kernel walks a broken partition
+        bad[30, 2, 777] = poison                                     # lands in the last piece
+        bad[31, :, ::7] = poison
+        with pytest.raises(McrError) as ei:
+            ctx.summarize(bad, "pcn")
+        assert ei.value.code == MCR_ENONFINITE
+        t = ctx.upload(bad[28:34], "pcn")
+        with pytest.raises(McrError) as ei:
+            ctx.summarize(t)
+        assert ei.value.code == MCR_ENONFINITE
+        t.free()
+    got3 = ctx.summarize(x, "pcn")                                   # the context is healthy afterwards
+    assert _bits_equal(got3["ess_bulk"], dev["ess_bulk"])
+    cnp = np.ascontiguousarray(np.transpose(x, (1, 2, 0)))           # [C][N][P]: not separable, single upload
+    got2 = ctx.summarize(cnp, "cnp")
+    for k in ("mean", "rhat", "ess_bulk", "lag_bulk"):
+        assert _bits_equal(got2[k], dev[k]), k
+    assert ctx.inflight == 0
