@@ -1190,6 +1190,8 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
         rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(Sr, kin, sizeof(double) * (size_t)P * Mr, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bad_count, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)a.part,
+                           (int)a.ntiles, (i64)P, bad);
     }
     {   // ascending order of the actual sample, then one merge-path pass over both
         Carve c2{reinterpret_cast<char*>(ctx->ws), base};
@@ -1197,6 +1199,8 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
         a.X = Xa;
         rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
         if (rc) return rc;
+        hipLaunchKernelGGL(k_bad_count, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)a.part,
+                           (int)a.ntiles, (i64)P, bad + P);
     }
     LAUNCH(ctx, K_TWO_SAMPLE, (k_two_sample<256, 16>), dim3((unsigned)nblk, (unsigned)P), dim3(256), 0,
            (const double*)Sr, (i64)Mr, (const double*)kin, (i64)Ma, part, nblk);
@@ -1204,11 +1208,12 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
            (const double*)part, nblk, (i64)P, (double)Mr * (double)Ma, d_ks, d_w);
     HIP_TRY(ctx, hipMemcpyAsync(ks, d_ks, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(w1, d_w, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> h_bad((size_t)2 * (size_t)P);
+    HIP_TRY(ctx, hipMemcpyAsync(h_bad.data(), bad, sizeof(double) * h_bad.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     prof_resolve(ctx);
-    (void)bad;
     for (i64 p = 0; p < P; ++p)
-        if (!(ks[p] == ks[p]) || !(w1[p] == w1[p]) || std::isinf(w1[p]))
+        if (h_bad[(size_t)p] != 0.0 || h_bad[(size_t)(P + p)] != 0.0 || !(ks[p] == ks[p]) || !(w1[p] == w1[p]) || std::isinf(w1[p]))
             return fail(ctx, MCR_ENONFINITE, "draws contain non-finite values");
     return MCR_OK;
 }

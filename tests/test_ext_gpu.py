@@ -38,6 +38,16 @@ def test_two_sample_matches_scipy(ctx):
     assert np.all(ks == 0.0) and np.all(w1 == 0.0)
     with pytest.raises(ValueError):
         ctx.two_sample(np.array([[1.0, np.nan]]), np.array([[1.0, 2.0]]))
+    # non-finite draws in long (multi-tile) samples, either side, are reported and never walked as a partition
+    big_r, big_a = rng.normal(size=(3, 40000)), rng.normal(size=(3, 25000))
+    for poison in (np.nan, np.inf, -np.inf):
+        for side in (0, 1):
+            r, a = big_r.copy(), big_a.copy()
+            (r if side == 0 else a)[1, ::11] = poison
+            with pytest.raises(ValueError):
+                ctx.two_sample(r, a)
+    ks, w1 = ctx.two_sample(big_r, big_a)
+    assert np.all(np.isfinite(ks)) and np.all(np.isfinite(w1))
 
 
 def test_covariance_mfma_matches_numpy(ctx):
