@@ -476,3 +476,17 @@ def test_host_upload_in_pieces(ctx, oracle):
     for k in ("mean", "rhat", "ess_bulk", "lag_bulk"):
         assert _bits_equal(got2[k], dev[k]), k
     assert ctx.inflight == 0
+
+
+def test_nonfinite_in_long_ragged_chains(ctx):
+    """mcr_diagnose_chains with NaN / Inf in chains that span several sort tiles (and unequal lengths)."""
+    from mcmc_ref_hip._ffi import McrError, MCR_ENONFINITE
+    rng = np.random.default_rng(8)
+    for poison in (np.nan, np.inf):
+        chains = [rng.normal(size=n) for n in (30000, 25000, 30000, 28000)]
+        chains[2][12345] = poison
+        with pytest.raises(McrError) as ei:
+            ctx.diagnose_chains(chains, min_chains=4)
+        assert ei.value.code == MCR_ENONFINITE
+    ok = ctx.diagnose_chains([rng.normal(size=n) for n in (30000, 25000, 30000, 28000)], min_chains=4)
+    assert abs(ok["rhat"] - 1.0) < 0.01
