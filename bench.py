@@ -239,15 +239,15 @@ def main():
         return last
 
     run(a.warmup)
-    # ---- timed region: exactly K steps (captured hipGraph replays, up to 4 in flight) ----
+    # ---- timed region: exactly K steps (rolling window of up to `inflight` calls over the context's lanes) ----
     barrier()
     t0 = time.perf_counter()
     last = run(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     # ---- same K steps again with a HIP event pair around every kernel launch (per-kernel roofline).
-    #      Events cannot sit inside a graph replay and, with two lanes, kernels of consecutive steps
-    #      overlap, which would inflate every per-kernel duration: this pass runs on a single-lane
+    #      With several lanes the kernels of consecutive steps overlap, which would inflate every
+    #      per-kernel duration: this pass runs on a single-lane
     #      context (same device buffer), so the durations are those of each kernel running alone
     #      and agree with rocprofv3 --kernel-trace of `MCR_LANES=1 python bench.py`. ----
     os.environ["MCR_LANES"] = "1"

@@ -94,8 +94,8 @@ int mcr_device_count(void);
 /* Creates a context bound to HIP device `device` (own non-blocking streams, lazily grown
  * workspaces).  Fails with MCR_ENODEVICE when no GPU is present: there is no CPU fallback.
  * Environment read here: MCR_LANES (streams + workspaces that consecutive calls rotate over,
- * default 4, max MCR_MAX_INFLIGHT), MCR_GRAPH=0 (no hipGraph capture / replay of the launch
- * sequence), MCR_WORKSPACE_MB (see mcr_set_workspace_limit).
+ * default 4, max MCR_MAX_INFLIGHT), MCR_GRAPH=1 (hipGraph capture / replay of the launch
+ * sequence; off by default), MCR_WORKSPACE_MB (see mcr_set_workspace_limit).
  * Limits: C <= 256 chains, C * N < 2^31 pooled draws per parameter (rank codes are 32-bit),
  * any number of parameters (chunked through the workspace). */
 int mcr_init(int device, mcr_ctx** out);

@@ -97,7 +97,7 @@ struct mcr_ctx {
     // hipGraph cache: the launch sequence of one summarize call is static for a given shape,
     // buffer set and slot, so it is captured once and replayed (removes ~5 us of host launch gap
     // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
-    bool graph_on = true;
+    bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
     std::vector<GraphEntry> graphs;
 };
 

@@ -490,3 +490,25 @@ def test_nonfinite_in_long_ragged_chains(ctx):
         assert ei.value.code == MCR_ENONFINITE
     ok = ctx.diagnose_chains([rng.normal(size=n) for n in (30000, 25000, 30000, 28000)], min_chains=4)
     assert abs(ok["rhat"] - 1.0) < 0.01
+
+
+def test_hipgraph_replay_path(oracle, monkeypatch):
+    """MCR_GRAPH=1 (capture once per shape / buffers / slot, then replay) gives the same bits as direct launches."""
+    from mcmc_ref_hip._ffi import Context
+    from mcmc_ref_hip import synth
+    x = synth.c1_model(4, 3000, 6, seed=17)
+    y = synth.c1_model(4, 700, 3, seed=18)
+    with Context(0) as plain:
+        a = [plain.summarize(x, "pcn"), plain.summarize(y, "pcn")]
+    monkeypatch.setenv("MCR_GRAPH", "1")
+    with Context(0) as g:
+        tx, ty = g.upload(x, "pcn"), g.upload(y, "pcn")
+        for _ in range(3):                                   # first round captures, later rounds replay
+            b = [g.summarize(tx), g.summarize(ty)]
+            for got, exp in zip(b, a):
+                for k in ("mean", "std", "q", "rhat", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail"):
+                    assert _bits_equal(got[k], exp[k]), k
+        bufs = [g.enqueue(tx) for _ in range(6)]
+        g.wait()
+        assert all(_bits_equal(bb.result()["ess_bulk"], a[0]["ess_bulk"]) for bb in bufs)
+        tx.free(); ty.free()
