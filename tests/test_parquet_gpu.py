@@ -275,3 +275,44 @@ def test_corrupted_files_fail_cleanly_or_decode_in_bounds(ctx):
                 outcomes["error"] += 1
     assert outcomes["error"] > 0 and outcomes["ok"] > 0, outcomes
     check_roundtrip(ctx, image(t))                             # the context is still healthy
+
+
+def test_random_tables_and_writer_options(ctx):
+    """Randomised schemas (column count, physical types, nullability flags, value distributions) and writer options
+    against pyarrow's decode."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.integers(1, 20000))
+        cols, fields = {}, []
+        for j in range(int(rng.integers(1, 9))):
+            kind = rng.integers(0, 7)
+            if kind == 0:
+                v = rng.normal(size=n) * 10.0 ** rng.integers(-6, 6)
+            elif kind == 1:
+                v = np.round(rng.normal(size=n), int(rng.integers(0, 3)))          # ties
+            elif kind == 2:
+                v = np.repeat(rng.normal(size=n // 97 + 1), 97)[:n]                # long runs
+            elif kind == 3:
+                v = rng.normal(size=n).astype(np.float32)
+            elif kind == 4:
+                v = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+            elif kind == 5:
+                v = rng.integers(-2**62, 2**62, n)
+            else:
+                v = (np.arange(n) % int(rng.integers(1, 5000))).astype(np.int64)   # periodic: compressible
+            name = f"c{j}"
+            cols[name] = v
+            fields.append(pa.field(name, pa.from_numpy_dtype(v.dtype), nullable=bool(rng.integers(0, 2))))
+        t = pa.table(cols, schema=pa.schema(fields))
+        kw = dict(compression=str(rng.choice(["snappy", "none"])),
+                  use_dictionary=bool(rng.integers(0, 2)),
+                  data_page_version=str(rng.choice(["1.0", "2.0"])))
+        if rng.integers(0, 2):
+            kw["row_group_size"] = int(rng.integers(1, n + 1))
+        if rng.integers(0, 2):
+            kw["data_page_size"] = int(rng.integers(64, 1 << 16))
+            kw["write_batch_size"] = int(rng.integers(1, 1024))
+        try:
+            check_roundtrip(ctx, image(t, **kw))
+        except AssertionError as exc:
+            raise AssertionError(f"case {case}: n={n} kw={kw} schema={t.schema}") from exc
