@@ -30,19 +30,27 @@ def main():
     from mcmc_ref_hip.convert import table_to_tensor
 
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    real_dir = Path(sys.argv[2]) if len(sys.argv) > 2 else None      # directory of real *.draws.parquet files
     ctx = _ffi.Context(0)
-    models = corpus.synthetic_corpus(seed=4711)
-    total_pd = sum(int(np.prod(m.shape)) for _, m in models)
     with tempfile.TemporaryDirectory() as td:
         paths = []
-        for name, x in models:
-            P, C, N = x.shape
-            cols = {"chain": np.repeat(np.arange(C), N), "draw": np.tile(np.arange(N), C)}
-            for i in range(P):
-                cols[f"p[{i + 1}]"] = x[i].reshape(-1)
-            path = Path(td) / f"{name}.draws.parquet"
-            pq.write_table(pa.table(cols), path)
-            paths.append(path)
+        if real_dir is not None:
+            paths = sorted(real_dir.glob("*.draws.parquet"))
+            total_pd = 0
+            for p in paths:
+                md = pq.ParquetFile(p).metadata
+                total_pd += md.num_rows * (md.num_columns - 2)
+        else:
+            models = corpus.synthetic_corpus(seed=4711)
+            total_pd = sum(int(np.prod(m.shape)) for _, m in models)
+            for name, x in models:
+                P, C, N = x.shape
+                cols = {"chain": np.repeat(np.arange(C), N), "draw": np.tile(np.arange(N), C)}
+                for i in range(P):
+                    cols[f"p[{i + 1}]"] = x[i].reshape(-1)
+                path = Path(td) / f"{name}.draws.parquet"
+                pq.write_table(pa.table(cols), path)
+                paths.append(path)
         file_bytes = sum(p.stat().st_size for p in paths)
 
         def arrow_pass():
@@ -99,8 +107,9 @@ def main():
             f.close()
     best_a = min(ta)
     out = {
-        "workload": f"{len(paths)} corpus-shaped Parquet files, {total_pd} param-draws, {file_bytes} file bytes "
-                    "(SNAPPY + RLE_DICTIONARY, pyarrow default writer), page cache warm",
+        "workload": (f"{len(paths)} REAL packaged corpus files" if real_dir is not None else
+                     f"{len(paths)} corpus-shaped Parquet files (synthetic draws)") +
+                    f", {total_pd} param-draws, {file_bytes} file bytes (SNAPPY + RLE_DICTIONARY), page cache warm",
         "identical_statistics": bool(same),
         "arrow_route_s": best_a[0], "arrow_decode_s": best_a[1], "arrow_upload_summarise_s": best_a[2],
         "native_route_s": min(tn),
