@@ -512,3 +512,30 @@ def test_hipgraph_replay_path(oracle, monkeypatch):
         g.wait()
         assert all(_bits_equal(bb.result()["ess_bulk"], a[0]["ess_bulk"]) for bb in bufs)
         tx.free(); ty.free()
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """One Context per thread (the documented threading model): concurrent calls do not disturb each other."""
+    import threading
+    from mcmc_ref_hip._ffi import Context
+    from mcmc_ref_hip import synth
+    xs = [synth.c1_model(4, 2000 + 500 * k, 5 + k, seed=30 + k) for k in range(2)]
+    exp = [oracle.summarize(x, "pcn") for x in xs]
+    out, errs = [None, None], []
+
+    def work(k):
+        try:
+            with Context(0) as c:
+                for _ in range(20):
+                    out[k] = c.summarize(xs[k], "pcn")
+        except Exception as exc:          # pragma: no cover
+            errs.append(exc)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        check_summary(out[k], exp[k], what=f"thread {k}")
