@@ -101,6 +101,23 @@ __device__ __forceinline__ i64 merge_path(FA a, i64 na, FB b, i64 nb, i64 diag)
     return lo;
 }
 
+// 32-bit variant for searches over LDS (tile-local indices): the loop carries two ints instead of two 64-bit
+// values -- half the selects per step of the per-thread partition search, which is ~1/3 of a merge level's VALU work.
+template <class FA, class FB>
+__device__ __forceinline__ int merge_path32(FA a, int na, FB b, int nb, int diag)
+{
+    int lo = diag > nb ? diag - nb : 0;
+    int hi = diag < na ? diag : na;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double ak = a(mid), bk = b(diag - 1 - mid);
+        const bool right = !(bk < ak);
+        lo = right ? mid + 1 : lo;
+        hi = right ? hi : mid;
+    }
+    return lo;
+}
+
 // The same split point found by a whole wave: 64 probes per step instead of one, so a search over
 // global memory costs ~log64(n) dependent round trips instead of log2(n).  All 64 lanes must call it
 // with identical arguments; every lane returns the result.

@@ -45,11 +45,11 @@ __global__ __launch_bounds__(NT) void k_two_sample(const double* __restrict__ rs
     const int total = (int)(d1 - d0);
     const int diag = (tid * VT < total) ? tid * VT : total;
     const int nout = (total - diag < VT) ? total - diag : VT;
-    auto LA = [&](i64 i) { return sk[pos16((int)i)]; };
-    auto LB = [&](i64 j) { return sk[pos16(ca + (int)j)]; };
+    auto LA = [&](int i) { return sk[pos16(i)]; };
+    auto LB = [&](int j) { return sk[pos16(ca + j)]; };
     // merge path over the pieces WITHOUT the look-ahead draws (they belong to later blocks)
     const int na = (int)(ai1 - ai0), nb = (int)(bi1 - bi0);
-    int ai = (int)merge_path(LA, (i64)na, LB, (i64)nb, (i64)diag);
+    int ai = merge_path32(LA, na, LB, nb, diag);
     int bi = diag - ai;
     double w = 0.0;
     i64 ksn = 0;   // max |i*Ma - j*Mr|: the KS statistic is this integer over Mr*Ma (an exact rational)

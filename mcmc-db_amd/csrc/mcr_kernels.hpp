@@ -356,9 +356,9 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
         const int run = VT * (coop >> 1);
         const int a0 = first * VT, b0 = a0 + run;
         const int diag = VT * (tid - first);
-        auto A = [&](i64 i) { return skey[pos16(a0 + (int)i)]; };
-        auto B = [&](i64 j) { return skey[pos16(b0 + (int)j)]; };
-        const int ai = (int)merge_path(A, (i64)run, B, (i64)run, (i64)diag);
+        auto A = [&](int i) { return skey[pos16(a0 + i)]; };
+        auto B = [&](int j) { return skey[pos16(b0 + j)]; };
+        const int ai = merge_path32(A, run, B, run, diag);
         int srcs[VT];
         serial_merge<VT>(skey, a0, run, b0, run, ai, diag - ai, VT, k, srcs);
 #pragma unroll
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
 
     const int diag = (tid * VT < total) ? tid * VT : total;
     const int nout = (total - diag < VT) ? total - diag : VT;
-    auto A = [&](i64 i) { return skey[pos16((int)i)]; };
-    auto B = [&](i64 j) { return skey[pos16(ca + (int)j)]; };
-    const int ai = (int)merge_path(A, (i64)ca, B, (i64)cb, (i64)diag);
+    auto A = [&](int i) { return skey[pos16(i)]; };
+    auto B = [&](int j) { return skey[pos16(ca + j)]; };
+    const int ai = merge_path32(A, ca, B, cb, diag);
     double k[VT];
     int srcs[VT];
     u32 ix[VT];
@@ -791,9 +791,9 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             const int a1 = sst[(ra + w < k) ? ra + w : k];
             const int b1 = sst[(ra + 2 * w < k) ? ra + 2 * w : k];
             const int na = a1 - a0, nb = b1 - a1, diag = chunk0 - a0;
-            auto A = [&](i64 i) { return skey[pos16(a0 + (int)i)]; };
-            auto Bf = [&](i64 j) { return skey[pos16(a1 + (int)j)]; };
-            const int ai = (int)merge_path(A, (i64)na, Bf, (i64)nb, (i64)diag);
+            auto A = [&](int i) { return skey[pos16(a0 + i)]; };
+            auto Bf = [&](int j) { return skey[pos16(a1 + j)]; };
+            const int ai = merge_path32(A, na, Bf, nb, diag);
             serial_merge<VT>(skey, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
 #pragma unroll
             for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
