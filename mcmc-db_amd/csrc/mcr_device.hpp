@@ -144,9 +144,11 @@ __device__ __forceinline__ i64 merge_path_wave(FA a, i64 na, FB b, i64 nb, i64 d
     return lo;
 }
 
-// LDS index padding: one pad slot per 16 elements, so that "thread t owns elements
-// [16t, 16t+16)" accesses (stride 17 doubles across lanes) are bank-conflict free.
-__device__ __forceinline__ int pos16(int e) { return e + (e >> 4); }
+// LDS index swizzle: the low four bits of an element index are XORed with the next four, so that "thread t owns
+// elements [16t, 16t+16)" accesses (element i of every thread at once) spread over all banks, and a run of 16
+// consecutive elements still occupies its own 16 slots.  One instruction cheaper per access than the pad slot per
+// 16 elements it replaced (arrays are still sized for that padding).
+__device__ __forceinline__ int pos16(int e) { return e ^ ((e >> 4) & 15); }
 
 // ---- counter-based generator (bench / stress tensor) ------------------------------------------
 __host__ __device__ __forceinline__ u64 splitmix64(u64 x)
