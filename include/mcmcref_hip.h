@@ -42,6 +42,7 @@ extern "C" {
 #define MCR_ENOMEM (-6)         /* host or device allocation failed */
 #define MCR_ENODEVICE (-7)      /* no usable HIP device / bad device index */
 #define MCR_ECOMM (-8)          /* RCCL error (multi-GPU gather) */
+#define MCR_ELAYOUT (-9)        /* mcr_summarize_files: rows not in (chain, draw) order or chains of unequal length */
 
 #define MCR_F64 0
 #define MCR_F32 1
@@ -254,6 +255,35 @@ int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs
  * order `_chains_from_table` produces (src/mcmc_ref/convert.py:150-161).  order is a host array. */
 int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t M, const int64_t* order,
                         double* dst_dev);
+
+/* ------------------------------------------------------------------------------------------------
+ * Many draws files -> statistics in ONE call (the per-model loop of reference.stats /
+ * diagnostics_for_model, src/mcmc_ref/reference.py:30-104, over a list of
+ * draws/<model>.draws.parquet files): mmap + footer parse on the host, one batched GPU decode, the
+ * chain / draw bookkeeping of convert._chains_from_table, same-shape neighbours summarised as one
+ * tensor, results in a host-side set.  Parameters = every numeric column except `chain` and `draw`,
+ * in schema order.  Files whose rows are not in (chain, draw) order, or whose chains differ in
+ * length while diagnostics are requested, end the call with MCR_ELAYOUT (use mcr_parquet_decode +
+ * mcr_gather_rows_dev + mcr_diagnose_chains for those).  diagnostics = 0: Backend.stats only
+ * (pooled mean / std / quantiles; any chain structure).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mcr_fileset mcr_fileset;
+#define MCR_FS_MEAN 0
+#define MCR_FS_STD 1
+#define MCR_FS_Q 2 /* [P][n_q] */
+#define MCR_FS_MEDIAN 3
+#define MCR_FS_RHAT 4
+#define MCR_FS_ESS_BULK 5
+#define MCR_FS_ESS_TAIL 6
+int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int min_chains,
+                        const double* quantiles, int n_q, int diagnostics, mcr_fileset** out);
+int mcr_fileset_size(const mcr_fileset* fs);
+int64_t mcr_fileset_params(const mcr_fileset* fs, int file);
+int64_t mcr_fileset_chains(const mcr_fileset* fs, int file);
+int64_t mcr_fileset_draws(const mcr_fileset* fs, int file); /* draws per chain (of the first chain when they differ) */
+const char* mcr_fileset_param_name(const mcr_fileset* fs, int file, int64_t param);
+const double* mcr_fileset_field(const mcr_fileset* fs, int file, int field); /* P doubles (MCR_FS_Q: P * n_q) */
+void mcr_fileset_free(mcr_fileset* fs);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <exception>
+#include <memory>
+#include <string>
 #include <functional>
 #include <new>
 #include <vector>
@@ -86,6 +92,7 @@ struct mcr_ctx {
     void* pq_stage = nullptr; size_t pq_stage_bytes = 0;
     void* pq_scratch = nullptr; size_t pq_scratch_bytes = 0;
     void* pq_tab = nullptr; size_t pq_tab_bytes = 0;
+    void* fs_arena = nullptr; size_t fs_arena_bytes = 0;   // mcr_summarize_files: decoded draws + chain / draw ids
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
     std::vector<int> order;  // busy slots in enqueue order
@@ -801,6 +808,7 @@ void mcr_free(mcr_ctx* ctx)
     if (ctx->pq_stage) hipFree(ctx->pq_stage);
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
     if (ctx->pq_tab) hipFree(ctx->pq_tab);
+    if (ctx->fs_arena) hipFree(ctx->fs_arena);
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
@@ -1527,5 +1535,208 @@ int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t 
     prof_resolve(ctx);
     return MCR_OK;
 }
+
+
+// ---- many files in one call -------------------------------------------------------------------------------
+
+struct mcr_fileset {
+    struct Entry {
+        std::vector<std::string> names;
+        i64 C = 0, N = 0;
+        std::vector<double> f[7];          // MCR_FS_* fields
+    };
+    std::vector<Entry> files;
+};
+
+namespace {
+struct MappedFile {
+    int fd = -1; void* map = MAP_FAILED; size_t len = 0; mcr_parquet* pq = nullptr;
+    ~MappedFile() {
+        if (pq) mcr_parquet_close(pq);
+        if (map != MAP_FAILED) munmap(map, len);
+        if (fd >= 0) close(fd);
+    }
+};
+}  // namespace
+
+int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int min_chains, const double* quantiles,
+                        int n_q, int diagnostics, mcr_fileset** out)
+{
+    namespace pq = mcr::pq;
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (!out || n_paths < 0 || (n_paths > 0 && !paths)) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (min_chains < 1) return fail(ctx, MCR_EMINCHAINS_ARG, "min_chains must be >= 1; got %d", min_chains);
+    if (n_q < 0 || n_q > MCR_MAX_QUANTILES || (n_q > 0 && !quantiles)) return fail(ctx, MCR_EINVAL, "bad quantile list");
+    if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_summarize_files with summaries in flight");
+    try {
+        std::vector<MappedFile> mf((size_t)n_paths);
+        struct Plan { std::vector<int> cols; int chain = -1, draw = -1; i64 M = 0; size_t off = 0, ioff = 0; i64 C = 0, N = 0; };
+        std::vector<Plan> plan((size_t)n_paths);
+        size_t arena = 0, ids = 0;
+        // 1. map + parse
+        for (int i = 0; i < n_paths; ++i) {
+            MappedFile& m = mf[(size_t)i];
+            m.fd = open(paths[i], O_RDONLY);
+            struct stat st;
+            if (m.fd < 0 || fstat(m.fd, &st) != 0) return fail(ctx, MCR_EINVAL, "cannot open %s", paths[i]);
+            m.len = (size_t)st.st_size;
+            if (m.len == 0) return fail(ctx, MCR_EINVAL, "parquet: %s is empty", paths[i]);
+            m.map = mmap(nullptr, m.len, PROT_READ, MAP_PRIVATE, m.fd, 0);
+            if (m.map == MAP_FAILED) return fail(ctx, MCR_EINVAL, "cannot map %s", paths[i]);
+            int rc = mcr_parquet_open(ctx, m.map, m.len, &m.pq);
+            if (rc) { char msg[400]; snprintf(msg, sizeof msg, "%s", ctx->err); return fail(ctx, rc, "%s: %s", paths[i], msg); }
+            const pq::File& f = m.pq->f;
+            Plan& pl = plan[(size_t)i];
+            for (int c = 0; c < (int)f.cols.size(); ++c) {
+                const int ty = f.cols[(size_t)c].type;
+                const bool numeric = ty == pq::T_INT32 || ty == pq::T_INT64 || ty == pq::T_FLOAT || ty == pq::T_DOUBLE;
+                if (f.cols[(size_t)c].name == "chain") pl.chain = c;
+                else if (f.cols[(size_t)c].name == "draw") pl.draw = c;
+                else if (numeric) pl.cols.push_back(c);
+            }
+            if (pl.chain < 0 || pl.draw < 0) return fail(ctx, MCR_EINVAL, "%s: no chain / draw columns", paths[i]);
+            pl.M = f.num_rows;
+            pl.off = arena; arena += pl.cols.size() * (size_t)pl.M * 8;
+            pl.ioff = ids; ids += (size_t)2 * (size_t)pl.M * 8;
+        }
+        // 2. one batched decode into the arena ([P][M] per file, packed) + chain / draw ids behind it
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const size_t ids_base = align_up(arena, 256);
+        int rc = ensure_buf(ctx, &ctx->fs_arena, &ctx->fs_arena_bytes, ids_base + ids + 256);
+        if (rc) return rc;
+        char* base = (char*)ctx->fs_arena;
+        std::vector<mcr_parquet_request> reqs;
+        for (int i = 0; i < n_paths; ++i) {
+            const Plan& pl = plan[(size_t)i];
+            for (size_t j = 0; j < pl.cols.size(); ++j)
+                reqs.push_back(mcr_parquet_request{mf[(size_t)i].pq, pl.cols[j], MCR_PQ_F64, base + pl.off + j * (size_t)pl.M * 8});
+            reqs.push_back(mcr_parquet_request{mf[(size_t)i].pq, pl.chain, MCR_PQ_I64, base + ids_base + pl.ioff});
+            reqs.push_back(mcr_parquet_request{mf[(size_t)i].pq, pl.draw, MCR_PQ_I64, base + ids_base + pl.ioff + (size_t)pl.M * 8});
+        }
+        rc = mcr_parquet_decode(ctx, reqs.data(), (int)reqs.size());
+        if (rc) return rc;
+        std::vector<int64_t> h_ids(ids / 8);
+        if (ids) {
+            HIP_TRY(ctx, hipMemcpyAsync(h_ids.data(), base + ids_base, ids, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        // 3. chain / draw bookkeeping (convert._chains_from_table): rows must already be in (chain, draw) order
+        for (int i = 0; i < n_paths; ++i) {
+            Plan& pl = plan[(size_t)i];
+            const int64_t* ch = h_ids.data() + pl.ioff / 8;
+            const int64_t* dr = ch + pl.M;
+            i64 C = 0, first_len = -1, run = 0;
+            bool equal = true;
+            for (i64 r = 0; r < pl.M; ++r) {
+                const bool new_chain = r == 0 || ch[r] != ch[r - 1];
+                if (!new_chain && dr[r] < dr[r - 1]) return fail(ctx, MCR_ELAYOUT, "%s: rows are not in (chain, draw) order", paths[i]);
+                if (new_chain) {
+                    if (r > 0 && ch[r] < ch[r - 1]) return fail(ctx, MCR_ELAYOUT, "%s: rows are not in (chain, draw) order", paths[i]);
+                    if (r > 0) { if (first_len < 0) first_len = run; else if (run != first_len) equal = false; }
+                    ++C; run = 0;
+                }
+                ++run;
+            }
+            if (pl.M > 0) { if (first_len < 0) first_len = run; else if (run != first_len) equal = false; }
+            pl.C = C; pl.N = first_len < 0 ? 0 : first_len;
+            if (diagnostics && !pl.cols.empty()) {
+                if (C < min_chains) return fail(ctx, MCR_EMINCHAINS, "%s: R-hat diagnostics require at least %d chains; got %lld chain(s)", paths[i], min_chains, (long long)C);
+                if (!equal) return fail(ctx, MCR_ELAYOUT, "%s: chains of unequal length", paths[i]);
+            }
+            if (!diagnostics && !pl.cols.empty() && pl.M == 0) return fail(ctx, MCR_EINVAL, "%s: cannot compute stats of empty columns", paths[i]);
+        }
+        // 4. result set + jobs (runs of neighbouring files of one shape are one tensor)
+        std::unique_ptr<mcr_fileset> fs(new mcr_fileset());
+        fs->files.resize((size_t)n_paths);
+        for (int i = 0; i < n_paths; ++i) {
+            mcr_fileset::Entry& e = fs->files[(size_t)i];
+            const Plan& pl = plan[(size_t)i];
+            const size_t P = pl.cols.size();
+            for (int c : pl.cols) e.names.push_back(mf[(size_t)i].pq->f.cols[(size_t)c].name);
+            e.C = pl.C; e.N = pl.N;
+            for (int k = 0; k < 7; ++k) e.f[k].assign(k == MCR_FS_Q ? P * (size_t)n_q : P, NAN);
+        }
+        struct Job { int first, count; i64 C, N, P; };
+        std::vector<Job> jobs;
+        for (int i = 0; i < n_paths; ++i) {
+            const Plan& pl = plan[(size_t)i];
+            if (pl.cols.empty()) continue;
+            const i64 Cj = diagnostics ? pl.C : 1, Nj = diagnostics ? pl.N : pl.M;
+            if (!jobs.empty()) {
+                Job& j = jobs.back();
+                const Plan& last = plan[(size_t)(j.first + j.count - 1)];
+                if (j.first + j.count == i && j.C == Cj && j.N == Nj && last.off + last.cols.size() * (size_t)last.M * 8 == pl.off) {
+                    ++j.count; j.P += (i64)pl.cols.size();
+                    continue;
+                }
+            }
+            jobs.push_back(Job{i, 1, Cj, Nj, (i64)pl.cols.size()});
+        }
+        // per-job staging of the results (a job spans files; scattered back below)
+        std::vector<std::vector<double>> jf(jobs.size() * 7);
+        std::vector<std::vector<int64_t>> jl(jobs.size() * 2);
+        std::vector<int64_t> qlo((size_t)(n_q > 0 ? n_q : 1));
+        int err = MCR_OK;
+        char keep[512] = "";
+        for (size_t k = 0; k < jobs.size() && !err; ++k) {
+            const Job& j = jobs[k];
+            for (int q = 0; q < 7; ++q) jf[k * 7 + q].assign(q == MCR_FS_Q ? (size_t)j.P * (size_t)n_q : (size_t)j.P, NAN);
+            jl[k * 2].assign((size_t)j.P, 0); jl[k * 2 + 1].assign((size_t)j.P, 0);
+            mcr_summary o{};
+            o.mean = jf[k * 7 + MCR_FS_MEAN].data(); o.std = jf[k * 7 + MCR_FS_STD].data();
+            o.q = n_q > 0 ? jf[k * 7 + MCR_FS_Q].data() : nullptr; o.median = jf[k * 7 + MCR_FS_MEDIAN].data();
+            o.q_lo = qlo.data();
+            if (diagnostics) {
+                o.rhat = jf[k * 7 + MCR_FS_RHAT].data(); o.ess_bulk = jf[k * 7 + MCR_FS_ESS_BULK].data();
+                o.ess_tail = jf[k * 7 + MCR_FS_ESS_TAIL].data();
+                o.lag_bulk = jl[k * 2].data(); o.lag_tail = jl[k * 2 + 1].data();
+            }
+            if (ctx->n_inflight >= MCR_MAX_INFLIGHT) err = wait_one_impl(ctx);
+            if (!err)
+                err = enqueue_impl(ctx, base + plan[(size_t)j.first].off, MCR_F64, j.C, j.N, j.P, j.N, 1, j.C * j.N,
+                                   diagnostics ? min_chains : 1, quantiles, n_q, &o);
+            if (err) memcpy(keep, ctx->err, sizeof keep);
+        }
+        const int rw = wait_impl(ctx);
+        if (err) { memcpy(ctx->err, keep, sizeof keep); return err; }
+        if (rw) return rw;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            size_t p0 = 0;
+            for (int i = jobs[k].first; i < jobs[k].first + jobs[k].count; ++i) {
+                mcr_fileset::Entry& e = fs->files[(size_t)i];
+                const size_t P = e.names.size();
+                for (int q = 0; q < 7; ++q) {
+                    const size_t w = q == MCR_FS_Q ? (size_t)n_q : 1;
+                    if (w) memcpy(e.f[q].data(), jf[k * 7 + q].data() + p0 * w, P * w * sizeof(double));
+                }
+                p0 += P;
+            }
+        }
+        *out = fs.release();
+        return MCR_OK;
+    } catch (const std::exception& e) {
+        return fail(ctx, MCR_ENOMEM, "mcr_summarize_files: host allocation failed: %s", e.what());
+    }
+}
+
+int mcr_fileset_size(const mcr_fileset* fs) { return fs ? (int)fs->files.size() : -1; }
+static const mcr_fileset::Entry* fs_entry(const mcr_fileset* fs, int file)
+{
+    return (fs && file >= 0 && file < (int)fs->files.size()) ? &fs->files[(size_t)file] : nullptr;
+}
+int64_t mcr_fileset_params(const mcr_fileset* fs, int file) { const auto* e = fs_entry(fs, file); return e ? (int64_t)e->names.size() : -1; }
+int64_t mcr_fileset_chains(const mcr_fileset* fs, int file) { const auto* e = fs_entry(fs, file); return e ? e->C : -1; }
+int64_t mcr_fileset_draws(const mcr_fileset* fs, int file) { const auto* e = fs_entry(fs, file); return e ? e->N : -1; }
+const char* mcr_fileset_param_name(const mcr_fileset* fs, int file, int64_t param)
+{
+    const auto* e = fs_entry(fs, file);
+    return (e && param >= 0 && param < (int64_t)e->names.size()) ? e->names[(size_t)param].c_str() : nullptr;
+}
+const double* mcr_fileset_field(const mcr_fileset* fs, int file, int field)
+{
+    const auto* e = fs_entry(fs, file);
+    return (e && field >= 0 && field < 7) ? e->f[field].data() : nullptr;
+}
+void mcr_fileset_free(mcr_fileset* fs) { delete fs; }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ import numpy as np
 
 MCR_OK = 0
 MCR_EINVAL, MCR_EMINCHAINS, MCR_EMINCHAINS_ARG, MCR_ENONFINITE = -1, -2, -3, -4
-MCR_EHIP, MCR_ENOMEM, MCR_ENODEVICE, MCR_ECOMM = -5, -6, -7, -8
+MCR_EHIP, MCR_ENOMEM, MCR_ENODEVICE, MCR_ECOMM, MCR_ELAYOUT = -5, -6, -7, -8, -9
 MCR_F64, MCR_F32 = 0, 1
 MCR_MAX_QUANTILES = 32
 MCR_MAX_INFLIGHT = 8
@@ -104,6 +104,15 @@ SYMBOLS = {
     "mcr_parquet_page_info": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "mcr_parquet_decode": (C.c_int, [C.c_void_p, C.POINTER(ParquetRequest), C.c_int]),
     "mcr_gather_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, _I64, _I64, _ip, C.c_void_p]),
+    "mcr_summarize_files": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, _dp, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "mcr_fileset_size": (C.c_int, [C.c_void_p]),
+    "mcr_fileset_params": (C.c_int64, [C.c_void_p, C.c_int]),
+    "mcr_fileset_chains": (C.c_int64, [C.c_void_p, C.c_int]),
+    "mcr_fileset_draws": (C.c_int64, [C.c_void_p, C.c_int]),
+    "mcr_fileset_param_name": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int64]),
+    "mcr_fileset_field": (_dp, [C.c_void_p, C.c_int, C.c_int]),
+    "mcr_fileset_free": (None, [C.c_void_p]),
 }
 
 _lib = None

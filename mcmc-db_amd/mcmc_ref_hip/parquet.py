@@ -274,6 +274,51 @@ def _entry(r: dict, i: int, qs, diagnostics: bool) -> dict[str, float]:
     return e
 
 
+_FS_FIELDS = (("mean", 0), ("std", 1), ("rhat", 4), ("ess_bulk", 5), ("ess_tail", 6))
+
+
+def _summarize_paths(ctx: "_ffi.Context", paths: list[str], min_chains: int, qs: list[float], diagnostics: bool):
+    """All of summarize_files in ONE C call (mcr_summarize_files: mmap, parse, batched decode, layout check,
+    pipelined statistics).  Returns None when a file needs the general route (rows out of (chain, draw) order,
+    chains of unequal length)."""
+    L = ctx.lib
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    q = np.ascontiguousarray(qs, dtype=np.float64)
+    fs = C.c_void_p()
+    rc = L.mcr_summarize_files(ctx.handle, arr, len(paths), int(min_chains), q.ctypes.data_as(C.POINTER(C.c_double)),
+                               q.size, 1 if diagnostics else 0, C.byref(fs))
+    if rc == _ffi.MCR_ELAYOUT:
+        return None
+    if rc != _ffi.MCR_OK:
+        msg = (L.mcr_last_error(ctx.handle) or b"").decode()
+        if rc in (_ffi.MCR_EMINCHAINS, _ffi.MCR_EMINCHAINS_ARG, _ffi.MCR_ENONFINITE):
+            raise ValueError(msg.split(": ", 1)[-1] if rc == _ffi.MCR_EMINCHAINS else msg)
+        if "cannot compute stats of empty columns" in msg:
+            raise ValueError("cannot compute stats of empty columns")
+        raise McrError(rc, msg)
+    try:
+        out = []
+        nq = len(qs)
+        qkeys = [f"q{int(v * 100)}" for v in qs]
+        for i in range(L.mcr_fileset_size(fs)):
+            P = int(L.mcr_fileset_params(fs, i))
+            names = [L.mcr_fileset_param_name(fs, i, j).decode() for j in range(P)]
+            cols = {k: np.ctypeslib.as_array(L.mcr_fileset_field(fs, i, f), shape=(P,)).tolist() if P else []
+                    for k, f in _FS_FIELDS if diagnostics or f < 2}
+            qq = np.ctypeslib.as_array(L.mcr_fileset_field(fs, i, 2), shape=(P, nq)).tolist() if P and nq else [[]] * P
+            res = {}
+            for j, name in enumerate(names):
+                e = {"mean": cols["mean"][j], "std": cols["std"][j]}
+                e.update(zip(qkeys, qq[j]))
+                if diagnostics:
+                    e.update(rhat=cols["rhat"][j], ess_bulk=cols["ess_bulk"][j], ess_tail=cols["ess_tail"][j])
+                res[name] = e
+            out.append(res)
+        return out
+    finally:
+        L.mcr_fileset_free(fs)
+
+
 def summarize_files(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Iterable[str] | None] | None = None, *,
                     min_chains: int = 4, quantiles=(0.05, 0.5, 0.95), diagnostics: bool = True
                     ) -> list[dict[str, dict[str, float]]]:
@@ -285,6 +330,11 @@ def summarize_files(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Ite
     `convert._compute_diagnostics` + `Backend.stats` give for the same file).
     """
     qs = list(quantiles)
+    if sources and all(isinstance(s_, (str, os.PathLike)) for s_ in sources) and \
+            (params is None or all(p_ is None for p_ in params)):
+        fast = _summarize_paths(ctx, [os.fspath(s_) for s_ in sources], min_chains, qs, diagnostics)
+        if fast is not None:
+            return fast
     models = read_draws_many(ctx, sources, params)
     try:
         # Jobs: maximal runs of neighbouring models that sit back to back in the arena and share (C, N) are ONE

@@ -316,3 +316,42 @@ def test_random_tables_and_writer_options(ctx):
             check_roundtrip(ctx, image(t, **kw))
         except AssertionError as exc:
             raise AssertionError(f"case {case}: n={n} kw={kw} schema={t.schema}") from exc
+
+
+def test_one_call_file_batch_equals_the_general_route(ctx, tmp_path):
+    """mcr_summarize_files (paths in, statistics out, one C call) against the Python-orchestrated route over the same
+    files; files it cannot take (shuffled rows, ragged chains) fall back to that route transparently."""
+    from mcmc_ref_hip import parquet
+    rng = np.random.default_rng(77)
+    paths = []
+    for k, (C, N, P) in enumerate([(4, 500, 3), (4, 500, 2), (10, 100, 7), (4, 500, 1), (2, 1000, 4)]):
+        cols = {"chain": np.repeat(np.arange(C), N), "draw": np.tile(np.arange(N), C)}
+        for p in range(P):
+            cols[f"theta[{p + 1}]"] = rng.normal(size=C * N)
+        path = tmp_path / f"m{k}.draws.parquet"
+        pq.write_table(pa.table(cols), path)
+        paths.append(path)
+    for diag, mc in ((True, 2), (False, 4)):
+        fast = parquet.summarize_files(ctx, paths, min_chains=mc, diagnostics=diag)            # C entry point
+        assert parquet._summarize_paths(ctx, [str(p) for p in paths], mc, [0.05, 0.5, 0.95], diag) == fast
+        slow = parquet.summarize_files(ctx, [p.read_bytes() for p in paths], min_chains=mc, diagnostics=diag)
+        assert fast == slow
+        assert [list(f) for f in fast] == [[f"theta[{p + 1}]" for p in range(P)] for P in (3, 2, 7, 1, 4)]
+    with pytest.raises(ValueError, match="require at least 4 chains; got 2"):
+        parquet.summarize_files(ctx, paths, min_chains=4)
+    # a shuffled file and a ragged one: the C call declines (MCR_ELAYOUT), the general route answers
+    t = pq.read_table(paths[0]).take(pa.array(rng.permutation(2000)))
+    pq.write_table(t, tmp_path / "shuffled.draws.parquet")
+    assert parquet._summarize_paths(ctx, [str(tmp_path / "shuffled.draws.parquet")], 4, [0.5], True) is None
+    a = parquet.summarize_files(ctx, [tmp_path / "shuffled.draws.parquet"])[0]
+    b = parquet.summarize_files(ctx, [paths[0]])[0]
+    assert a == b
+    rag = pa.table({"chain": [0] * 40 + [1] * 30 + [2] * 35 + [3] * 40, "draw": list(range(40)) + list(range(30)) +
+                    list(range(35)) + list(range(40)), "a": rng.normal(size=145)})
+    pq.write_table(rag, tmp_path / "ragged.draws.parquet")
+    assert parquet._summarize_paths(ctx, [str(tmp_path / "ragged.draws.parquet")], 4, [0.5], True) is None
+    assert parquet._summarize_paths(ctx, [str(tmp_path / "ragged.draws.parquet")], 4, [0.5], False) is not None
+    r = parquet.summarize_files(ctx, [tmp_path / "ragged.draws.parquet"])[0]
+    assert set(r["a"]) == {"mean", "std", "q5", "q50", "q95", "rhat", "ess_bulk", "ess_tail"}
+    with pytest.raises(Exception):
+        parquet.summarize_files(ctx, [tmp_path / "missing.draws.parquet"])
