@@ -355,3 +355,27 @@ def test_one_call_file_batch_equals_the_general_route(ctx, tmp_path):
     assert set(r["a"]) == {"mean", "std", "q5", "q50", "q95", "rhat", "ess_bulk", "ess_tail"}
     with pytest.raises(Exception):
         parquet.summarize_files(ctx, [tmp_path / "missing.draws.parquet"])
+
+
+def test_file_batch_reports_the_broken_file(ctx, tmp_path):
+    from mcmc_ref_hip._ffi import McrError
+    from mcmc_ref_hip import parquet
+    rng = np.random.default_rng(5)
+    good = tmp_path / "good.draws.parquet"
+    pq.write_table(pa.table({"chain": np.repeat(np.arange(4), 100), "draw": np.tile(np.arange(100), 4),
+                             "x": rng.normal(size=400)}), good)
+    bad = tmp_path / "bad.draws.parquet"
+    img = bytearray(good.read_bytes())
+    img[-6] ^= 0xFF                                   # footer length
+    bad.write_bytes(bytes(img))
+    with pytest.raises(McrError, match="bad.draws.parquet"):
+        parquet.summarize_files(ctx, [good, bad])
+    (tmp_path / "empty.draws.parquet").write_bytes(b"")
+    with pytest.raises(McrError, match="empty"):
+        parquet.summarize_files(ctx, [good, tmp_path / "empty.draws.parquet"])
+    nochain = tmp_path / "nochain.draws.parquet"
+    pq.write_table(pa.table({"x": rng.normal(size=10)}), nochain)
+    with pytest.raises(McrError, match="chain / draw"):
+        parquet.summarize_files(ctx, [nochain])
+    ok = parquet.summarize_files(ctx, [good])[0]
+    assert set(ok) == {"x"} and abs(ok["x"]["rhat"] - 1) < 0.1
