@@ -11,8 +11,9 @@
  *   - every function returns MCR_OK (0) or a negative MCR_E* code and never throws/aborts;
  *     mcr_last_error(ctx) returns a human-readable message for the last failure on ctx.
  *   - the caller owns every host buffer; the library owns all device scratch in mcr_ctx.
- *   - one mcr_ctx == one GPU + one HIP stream.  Calls on one ctx must be serialised by the
- *     caller; different ctxs are independent (one process per GPU, or several ctxs in one).
+ *   - one mcr_ctx == one GPU + its HIP streams ("lanes", see mcr_init).  Calls on one ctx must be
+ *     serialised by the caller; different ctxs are independent (one process per GPU, one ctx per
+ *     thread, or several ctxs in one thread).
  *   - tensors are described by element strides (stride_c, stride_n, stride_p), so both the
  *     Arrow column layout [P][C][N] and `Draws.to_numpy` layout [C][N][P] (src/mcmc_ref/draws.py:28-29)
  *     are accepted without a host-side copy.
