@@ -276,6 +276,11 @@ typedef struct mcr_fileset mcr_fileset;
 #define MCR_FS_RHAT 4
 #define MCR_FS_ESS_BULK 5
 #define MCR_FS_ESS_TAIL 6
+#define MCR_FS_RHAT_BULK 7
+#define MCR_FS_RHAT_TAIL 8
+#define MCR_FS_LAG_BULK 9 /* truncation lags as doubles */
+#define MCR_FS_LAG_TAIL 10
+#define MCR_FS_FIELDS 11
 int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int min_chains,
                         const double* quantiles, int n_q, int diagnostics, mcr_fileset** out);
 int mcr_fileset_size(const mcr_fileset* fs);

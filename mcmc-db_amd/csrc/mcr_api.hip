@@ -1543,7 +1543,7 @@ struct mcr_fileset {
     struct Entry {
         std::vector<std::string> names;
         i64 C = 0, N = 0;
-        std::vector<double> f[7];          // MCR_FS_* fields
+        std::vector<double> f[MCR_FS_FIELDS];   // MCR_FS_* fields
     };
     std::vector<Entry> files;
 };
@@ -1654,7 +1654,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             const size_t P = pl.cols.size();
             for (int c : pl.cols) e.names.push_back(mf[(size_t)i].pq->f.cols[(size_t)c].name);
             e.C = pl.C; e.N = pl.N;
-            for (int k = 0; k < 7; ++k) e.f[k].assign(k == MCR_FS_Q ? P * (size_t)n_q : P, NAN);
+            for (int k = 0; k < MCR_FS_FIELDS; ++k) e.f[k].assign(k == MCR_FS_Q ? P * (size_t)n_q : P, NAN);
         }
         struct Job { int first, count; i64 C, N, P; };
         std::vector<Job> jobs;
@@ -1673,22 +1673,24 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             jobs.push_back(Job{i, 1, Cj, Nj, (i64)pl.cols.size()});
         }
         // per-job staging of the results (a job spans files; scattered back below)
-        std::vector<std::vector<double>> jf(jobs.size() * 7);
+        constexpr int NF = MCR_FS_FIELDS;
+        std::vector<std::vector<double>> jf(jobs.size() * NF);
         std::vector<std::vector<int64_t>> jl(jobs.size() * 2);
         std::vector<int64_t> qlo((size_t)(n_q > 0 ? n_q : 1));
         int err = MCR_OK;
         char keep[512] = "";
         for (size_t k = 0; k < jobs.size() && !err; ++k) {
             const Job& j = jobs[k];
-            for (int q = 0; q < 7; ++q) jf[k * 7 + q].assign(q == MCR_FS_Q ? (size_t)j.P * (size_t)n_q : (size_t)j.P, NAN);
+            for (int q = 0; q < NF; ++q) jf[k * NF + q].assign(q == MCR_FS_Q ? (size_t)j.P * (size_t)n_q : (size_t)j.P, NAN);
             jl[k * 2].assign((size_t)j.P, 0); jl[k * 2 + 1].assign((size_t)j.P, 0);
             mcr_summary o{};
-            o.mean = jf[k * 7 + MCR_FS_MEAN].data(); o.std = jf[k * 7 + MCR_FS_STD].data();
-            o.q = n_q > 0 ? jf[k * 7 + MCR_FS_Q].data() : nullptr; o.median = jf[k * 7 + MCR_FS_MEDIAN].data();
+            o.mean = jf[k * NF + MCR_FS_MEAN].data(); o.std = jf[k * NF + MCR_FS_STD].data();
+            o.q = n_q > 0 ? jf[k * NF + MCR_FS_Q].data() : nullptr; o.median = jf[k * NF + MCR_FS_MEDIAN].data();
             o.q_lo = qlo.data();
             if (diagnostics) {
-                o.rhat = jf[k * 7 + MCR_FS_RHAT].data(); o.ess_bulk = jf[k * 7 + MCR_FS_ESS_BULK].data();
-                o.ess_tail = jf[k * 7 + MCR_FS_ESS_TAIL].data();
+                o.rhat = jf[k * NF + MCR_FS_RHAT].data(); o.ess_bulk = jf[k * NF + MCR_FS_ESS_BULK].data();
+                o.ess_tail = jf[k * NF + MCR_FS_ESS_TAIL].data();
+                o.rhat_bulk = jf[k * NF + MCR_FS_RHAT_BULK].data(); o.rhat_tail = jf[k * NF + MCR_FS_RHAT_TAIL].data();
                 o.lag_bulk = jl[k * 2].data(); o.lag_tail = jl[k * 2 + 1].data();
             }
             if (ctx->n_inflight >= MCR_MAX_INFLIGHT) err = wait_one_impl(ctx);
@@ -1700,14 +1702,20 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
         const int rw = wait_impl(ctx);
         if (err) { memcpy(ctx->err, keep, sizeof keep); return err; }
         if (rw) return rw;
+        if (diagnostics)
+            for (size_t k = 0; k < jobs.size(); ++k)
+                for (size_t p = 0; p < (size_t)jobs[k].P; ++p) {
+                    jf[k * NF + MCR_FS_LAG_BULK][p] = (double)jl[k * 2][p];
+                    jf[k * NF + MCR_FS_LAG_TAIL][p] = (double)jl[k * 2 + 1][p];
+                }
         for (size_t k = 0; k < jobs.size(); ++k) {
             size_t p0 = 0;
             for (int i = jobs[k].first; i < jobs[k].first + jobs[k].count; ++i) {
                 mcr_fileset::Entry& e = fs->files[(size_t)i];
                 const size_t P = e.names.size();
-                for (int q = 0; q < 7; ++q) {
+                for (int q = 0; q < NF; ++q) {
                     const size_t w = q == MCR_FS_Q ? (size_t)n_q : 1;
-                    if (w) memcpy(e.f[q].data(), jf[k * 7 + q].data() + p0 * w, P * w * sizeof(double));
+                    if (w) memcpy(e.f[q].data(), jf[k * NF + q].data() + p0 * w, P * w * sizeof(double));
                 }
                 p0 += P;
             }
@@ -1735,7 +1743,7 @@ const char* mcr_fileset_param_name(const mcr_fileset* fs, int file, int64_t para
 const double* mcr_fileset_field(const mcr_fileset* fs, int file, int field)
 {
     const auto* e = fs_entry(fs, file);
-    return (e && field >= 0 && field < 7) ? e->f[field].data() : nullptr;
+    return (e && field >= 0 && field < MCR_FS_FIELDS) ? e->f[field].data() : nullptr;
 }
 void mcr_fileset_free(mcr_fileset* fs) { delete fs; }
 

@@ -128,3 +128,54 @@ def summarize_models(ctx, models: Sequence[tuple[np.ndarray, str]], rank: int = 
     drain()
     local = np.concatenate(recs, axis=0) if recs else np.empty((0, RECORD_DOUBLES))
     return gather_records(local, dist)
+
+
+def summarize_paths(ctx, paths: Sequence, rank: int = 0, world: int = 1, dist=None, min_chains: int = 4,
+                    device=None) -> np.ndarray:
+    """The corpus straight from disk on N GPUs: `paths` (draws/<model>.draws.parquet files, the same list on every
+    rank) are assigned to ranks by greedy LPT over file size, each rank turns its share into statistics with ONE
+    `mcr_summarize_files` call (native Parquet ingest + kernels), and one all_gather of the 128-byte records puts
+    every model's summary on every rank.  `model_idx` in the records indexes `paths`."""
+    import ctypes as C
+    import os
+    from . import _ffi, parquet
+    paths = [os.fspath(p) for p in paths]
+    mine = plan_shards([float(os.path.getsize(p)) for p in paths], world)[rank]
+    qs = np.array([0.05, 0.5, 0.95])
+    recs = []
+    if mine:
+        L = ctx.lib
+        arr = (C.c_char_p * len(mine))(*[paths[i].encode() for i in mine])
+        fs = C.c_void_p()
+        rc = L.mcr_summarize_files(ctx.handle, arr, len(mine), int(min_chains), qs.ctypes.data_as(C.POINTER(C.c_double)),
+                                   3, 1, C.byref(fs))
+        if rc == _ffi.MCR_OK:
+            try:
+                for k, i in enumerate(mine):
+                    P = int(L.mcr_fileset_params(fs, k))
+                    if P == 0:
+                        continue
+                    fld = lambda f, w=1: np.ctypeslib.as_array(L.mcr_fileset_field(fs, k, f), shape=(P * w,)).copy()  # noqa: E731
+                    q = fld(2, 3).reshape(P, 3)
+                    rec = np.empty((P, RECORD_DOUBLES))
+                    cols = [fld(0), fld(1), q[:, 0], q[:, 1], q[:, 2], fld(7), fld(8), fld(4), fld(5), fld(6), fld(9), fld(10),
+                            np.full(P, float(L.mcr_fileset_chains(fs, k))), np.full(P, float(L.mcr_fileset_draws(fs, k))),
+                            np.arange(P, dtype=np.float64), np.full(P, float(i))]
+                    for j, c in enumerate(cols):
+                        rec[:, j] = c
+                    recs.append(rec)
+            finally:
+                L.mcr_fileset_free(fs)
+        elif rc == _ffi.MCR_ELAYOUT:          # shuffled rows somewhere in the share: the per-file route (device gather)
+            for d, i in zip(parquet.read_draws_many(ctx, [paths[i] for i in mine]), mine):
+                try:
+                    if d.tensor is None:
+                        raise ValueError(f"{paths[i]}: chains of unequal length")
+                    r = ctx.summarize(d.tensor, min_chains=min_chains)
+                    recs.append(pack_records(r, i, len(d.counts), int(d.counts[0])))
+                finally:
+                    d.free()
+        else:
+            ctx._check(rc)
+    local = np.concatenate(recs, axis=0) if recs else np.empty((0, RECORD_DOUBLES))
+    return gather_records(local, dist, device=device)
