@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extreme shapes and value ranges against the oracle (development aid; second call of each shape is timed)."""
 import sys, time
-sys.path[:0]=['/root/repo','/root/repo/mcmc-db_amd']
+from pathlib import Path; ROOT = Path(__file__).resolve().parents[2]; sys.path[:0] = [str(ROOT), str(ROOT / 'mcmc-db_amd')]
 import numpy as np
 from mcmc_ref_hip import _ffi
 from oracle import oracle as orc

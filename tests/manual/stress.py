@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """BASELINE config 4 (stress): 4 x 100000 x P fp32 synthetic draws generated on the device.
 
-  python tools/stress.py --params 10000        # 16 GB tensor: streaming-moments roofline + full pipeline
+  python tests/manual/stress.py --params 10000        # 16 GB tensor: streaming-moments roofline + full pipeline
 Reports the moments kernel's achieved HBM GB/s (algorithmic bytes = 4 B per param-draw) and the
 full-pipeline param-draws/s, and checks a 16-parameter slice against the CPU oracle.
 """
 import argparse, json, sys, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
 from mcmc_ref_hip import _ffi
 
