@@ -1,8 +1,8 @@
 """All packaged models (real draws files of the reference corpus, parquet-cpp-arrow 23.0.0) through the native Parquet
 ingest and the kernels, against the diagnostics the reference itself packaged in meta.json (1 380
-checkable goldens).  The 42 MB of data files are not committed: the test runs only where
-tests/golden/_full_corpus/{draws,meta} has been populated (one-off validation recorded in DESIGN.md) and is skipped
-otherwise; the committed subset is tests/golden/models + tests/golden/parquet."""
+checkable goldens).  The data files (57 draws files, 63 meta files: DATA, not source) are committed under
+tests/golden/corpus/{draws,meta} (tests/golden/make_corpus_fixture.py copies them), so BASELINE config 3
+"full packaged mcmc-ref-data reference set, 1 MI355X" runs in every `-m gpu` pass."""
 from __future__ import annotations
 
 import json
@@ -13,16 +13,15 @@ import pytest
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
-ROOT = GOLDEN / "_full_corpus"
+ROOT = GOLDEN / "corpus"
 
 
-@pytest.mark.skipif(not (ROOT / "draws").is_dir(), reason="full corpus data files not present")
 def test_every_packaged_golden_through_native_ingest_and_kernels():
     import pyarrow.parquet as pq
     from mcmc_ref_hip import _ffi, parquet
     from mcmc_ref_hip.convert import _checks, table_to_tensor
     paths = sorted((ROOT / "draws").glob("*.draws.parquet"))
-    assert len(paths) >= 50
+    assert len(paths) == 57
     ctx = _ffi.Context(0)
     res = parquet.summarize_files(ctx, paths, min_chains=4)
     n_vals, worst, n_exact = 0, 0.0, 0

@@ -1,7 +1,6 @@
 """Pin the oracle against EVERY packaged golden the reference holds: the
-meta.json["diagnostics"] of all models whose draws are present under /root/reference.  Runs only
-where the reference checkout exists (the build container); reads data files only (Parquet + JSON),
-imports no reference code.  The GPU box never sees this path (it has the six committed fixtures)."""
+meta.json["diagnostics"] of all 57 models whose draws the reference packages.  Reads the committed copies of
+those data files (tests/golden/corpus, Parquet + JSON; tests/golden/make_corpus_fixture.py), imports no reference code."""
 from __future__ import annotations
 
 import json
@@ -10,11 +9,9 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from conftest import rel_close
+from conftest import GOLDEN, rel_close
 
-DATA = Path("/root/reference/packages/mcmc-ref-data/src/mcmc_ref_data/data")
-
-pytestmark = pytest.mark.skipif(not (DATA / "draws").exists(), reason="reference data not present")
+DATA = GOLDEN / "corpus"
 
 
 def test_all_packaged_goldens(oracle):
@@ -45,3 +42,16 @@ def test_all_packaged_goldens(oracle):
         n_models += 1
     assert n_models >= 57 and n_values >= 1380
     assert n_bit >= 1100 and worst < 1e-13            # SURVEY: 1143 / 1380 bit-equal, max deviation 6.4e-15
+
+
+def test_committed_corpus_files_match_the_reference_manifest():
+    """The reference pins its packaged files by sha256 (provenance_manifest.json, checked by its own
+    tests/integration/test_package_data_completeness.py:82-97): the committed copies are those files."""
+    import hashlib
+    manifest = json.loads((DATA / "provenance_manifest.json").read_text())["files"]
+    n = 0
+    for sub, pat in (("draws", "*.draws.parquet"), ("meta", "*.meta.json")):
+        for f in sorted((DATA / sub).glob(pat)):
+            assert manifest[f"{sub}/{f.name}"] == hashlib.sha256(f.read_bytes()).hexdigest(), f.name
+            n += 1
+    assert n == 57 + 63
