@@ -1418,8 +1418,9 @@ int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs
         }
         size_t stage_total = 0;
         for (Span& s : merged) { s.stage_off = align_up(stage_total, 256); stage_total = s.stage_off + (size_t)(s.end - s.start); }
-        auto stage_of = [&](const pq::File* f, u64 off) -> size_t {
-            for (const Span& s : merged) if (s.f == f && off >= s.start && off < s.end) return s.stage_off + (size_t)(off - s.start);
+        // staged position of the file bytes [off, off + n): the WHOLE payload must lie inside one uploaded span
+        auto stage_of = [&](const pq::File* f, u64 off, u64 n) -> size_t {
+            for (const Span& s : merged) if (s.f == f && off >= s.start && off + n <= s.end) return s.stage_off + (size_t)(off - s.start);
             return (size_t)-1;
         };
         // 2. page table
@@ -1441,7 +1442,7 @@ int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs
                     const u32 lvl = v2 ? pg.rep_bytes + pg.def_bytes : 0;
                     const bool comp = pg.codec == pq::CODEC_SNAPPY && (!v2 || pg.v2_compressed);
                     if (pg.uncomp_size < lvl) return fail(ctx, MCR_EINVAL, "parquet: v2 page smaller than its levels");
-                    d.src_off = stage_of(&f, pg.payload_off);
+                    d.src_off = stage_of(&f, pg.payload_off, pg.comp_size);
                     if (pg.comp_size > 0 && d.src_off == (u64)(size_t)-1) return fail(ctx, MCR_EINVAL, "parquet: page outside its column chunk");
                     d.comp_size = pg.comp_size - lvl; d.uncomp_size = pg.uncomp_size - lvl;
                     d.num_values = pg.num_values; d.lvl_bytes = lvl; d.def_bytes = v2 ? pg.def_bytes : 0;

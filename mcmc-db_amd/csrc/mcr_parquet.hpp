@@ -77,8 +77,15 @@ struct Thrift {
             case 4: case 5: case 6: varint(); break;
             case 7: if (end - p < 8) ok = false; else p += 8; break;
             case 8: { const unsigned char* s; size_t n; binary(&s, &n); break; }
-            case 9: case 10: { int et; u64 n; list_header(&et, &n); for (u64 i = 0; i < n && ok; ++i) { if (et == 1 || et == 2) byte(); else skip(et, depth + 1); } break; }
-            case 11: { const u64 n = varint(); if (n) { const unsigned char kv = byte(); for (u64 i = 0; i < n && ok; ++i) { skip(kv >> 4, depth + 1); skip(kv & 15, depth + 1); } } break; }
+            // every element occupies at least one byte (a bool inside a container is one byte, unlike a bool field,
+            // which lives in its header): a count larger than what is left is a damaged footer, not a long loop
+            case 9: case 10: { int et; u64 n; list_header(&et, &n); if (n > (u64)(end - p)) { ok = false; break; }
+                               for (u64 i = 0; i < n && ok; ++i) { if (et == 1 || et == 2) byte(); else skip(et, depth + 1); } break; }
+            case 11: { const u64 n = varint(); if (n > (u64)(end - p)) { ok = false; break; }
+                       if (n) { const unsigned char kv = byte(); const int kt = kv >> 4, vt = kv & 15;
+                                for (u64 i = 0; i < n && ok; ++i) {
+                                    if (kt == 1 || kt == 2) byte(); else skip(kt, depth + 1);
+                                    if (vt == 1 || vt == 2) byte(); else skip(vt, depth + 1); } } break; }
             case 12: { int id = 0; for (;;) { const int t = field(&id); if (!t || !ok) break; skip(t, depth + 1); } break; }
             default: ok = false;
         }
@@ -261,6 +268,9 @@ inline bool open(File& f, const void* bytes, size_t len)
                 Page pg; pg.col = (int)c; pg.codec = m.codec;
                 if (!parse_page_header(f, off, pg)) return false;
                 off = pg.payload_off + pg.comp_size;
+                // only the chunks of the requested columns are uploaded: a page that runs past its chunk would make the
+                // decode kernels read outside the staged bytes
+                if (off > end) return fail(f, "page of column '" + f.cols[c].name + "' extends beyond its column chunk");
                 if (pg.kind == PAGE_INDEX) continue;
                 if (pg.kind == PAGE_DICT) { dict = (int)f.pages.size(); dict_count = pg.num_values; }
                 else if (pg.kind == PAGE_DATA || pg.kind == PAGE_DATA_V2) {

@@ -186,25 +186,26 @@ def read_draws_many(ctx: "_ffi.Context", sources: Sequence, params: Sequence[Ite
     owned = [not isinstance(s, ParquetFile) for s in sources]
     try:
         reqs, plan, bufs = [], [], []
-        wants, sizes = [], []
+        wants, sizes, colidx, ididx = [], [], [], []
         for k, f in enumerate(files):
             want = list(params[k]) if params is not None and params[k] is not None else \
                 [n for n, t in zip(f.column_names, f.column_types) if n not in ("chain", "draw") and t in NUMERIC]
             wants.append(want)
+            colidx.append([f.index(n) for n in want])      # KeyError for an unknown name BEFORE any device allocation
+            ididx.append((f.index("chain"), f.index("draw")))
             sizes.append(len(want) * f.num_rows * 8)       # packed: same-shape neighbours form ONE [P][C][N] tensor
         arena = _Arena(ctx, sum(sizes))
         id_rows = sum(f.num_rows for f in files)
         ids_all = DeviceBuffer(ctx, max(2 * id_rows * 8, 8))
         off = ioff = 0
-        for f, want, size in zip(files, wants, sizes):
-            cols = [f.index(n) for n in want]
+        for f, want, size, cols, (i_chain, i_draw) in zip(files, wants, sizes, colidx, ididx):
             M = f.num_rows
             buf = arena.view(off, len(cols) * M * 8)
             base, ibase = buf.ptr.value, ids_all.ptr.value + ioff * 8
             for j, c in enumerate(cols):
                 reqs.append((f, c, MCR_PQ_F64, base + j * M * 8))
-            reqs.append((f, f.index("chain"), MCR_PQ_I64, ibase))
-            reqs.append((f, f.index("draw"), MCR_PQ_I64, ibase + M * 8))
+            reqs.append((f, i_chain, MCR_PQ_I64, ibase))
+            reqs.append((f, i_draw, MCR_PQ_I64, ibase + M * 8))
             plan.append((want, M, buf, ioff))
             bufs.append(buf)
             off += size

@@ -118,3 +118,39 @@ def test_fuzzed_footers_never_crash():
             ParquetFile(bytes(b)).close()
         except McrError:
             pass
+
+
+def inflated_last_page_image() -> bytes:
+    """Two uncompressed PLAIN columns of 1000 doubles; the compressed_page_size in the page header of column `a`
+    is raised to 8191 (same varint length), so its page runs past its column chunk, into `b`."""
+    img = bytearray(image(pa.table({"a": np.arange(1000.0), "b": np.arange(1000.0) + 0.5}), compression="none",
+                          use_dictionary=False, write_statistics=False))
+    at = pq.ParquetFile(io.BytesIO(bytes(img))).metadata.row_group(0).column(0).data_page_offset
+    # page header: 15 00 (DATA_PAGE)  15 vv (uncompressed_page_size)  15 vv (compressed_page_size), 2-byte varints
+    assert img[at:at + 3] == b"\x15\x00\x15" and img[at + 5] == 0x15 and img[at + 3:at + 5] == img[at + 6:at + 8]
+    assert img[at + 3] & 0x80 and not img[at + 4] & 0x80
+    img[at + 6:at + 8] = bytes([0xFE, 0x7F])      # varint(zigzag(8191)) > the 8 0xx bytes the chunk holds
+    return bytes(img)
+
+
+def test_page_running_past_its_column_chunk_is_rejected():
+    """only the chunks of the requested columns are staged on the device, so a page payload that extends
+    beyond its chunk (a damaged compressed_page_size, an understated total_compressed_size) must fail in open()."""
+    with pytest.raises(McrError, match="extends beyond its column chunk"):
+        ParquetFile(inflated_last_page_image())
+
+
+def test_thrift_containers_with_huge_counts_fail_fast():
+    """A footer whose unknown field is a map<bool,bool> / list with an absurd count must not spin."""
+    import time
+    img = image(pa.table({"x": np.arange(10.0)}))
+    flen = int.from_bytes(img[-8:-4], "little")
+    foot = img[len(img) - 8 - flen:len(img) - 8]
+    for evil in (bytes([0xFB]) + b"\xff" * 9 + b"\x01" + bytes([0x11]),      # field +15: map, count 2^63-1, <bool,bool>
+                 bytes([0xF9, 0xF1]) + b"\xff" * 9 + b"\x01"):                # field +15: list<bool>, count 2^63-1
+        new_foot = evil + foot
+        b = img[:len(img) - 8 - flen] + new_foot + len(new_foot).to_bytes(4, "little") + b"PAR1"
+        t0 = time.perf_counter()
+        with pytest.raises(McrError):
+            ParquetFile(b)
+        assert time.perf_counter() - t0 < 1.0

@@ -277,6 +277,17 @@ def test_corrupted_files_fail_cleanly_or_decode_in_bounds(ctx):
     check_roundtrip(ctx, image(t))                             # the context is still healthy
 
 
+def test_column_subset_of_a_file_with_an_inflated_page_is_rejected(ctx):
+    """with a column subset only that column's chunk is staged; a page claiming more bytes than its chunk
+    holds must be refused before any kernel reads past the staging buffer."""
+    from mcmc_ref_hip._ffi import McrError
+    from mcmc_ref_hip.parquet import read_columns
+    from test_parquet_cpu import inflated_last_page_image
+    with pytest.raises(McrError, match="extends beyond its column chunk"):
+        read_columns(ctx, inflated_last_page_image(), columns=["a"])
+    check_roundtrip(ctx, image(pa.table({"a": np.arange(1000.0), "b": np.arange(1000.0) + 0.5})))
+
+
 def test_random_tables_and_writer_options(ctx):
     """Randomised schemas (column count, physical types, nullability flags, value distributions) and writer options
     against pyarrow's decode."""
