@@ -1,8 +1,10 @@
 """Backend registry with the MI355X "hip" backend.
 
 Mirrors src/mcmc_ref/backends.py:14-55 of the reference: the `Backend` protocol, the frozen
-`BackendSpec`, the `BACKENDS` dict and `get_backend(name)` with the same error text.  The only
-entry is "hip"; `register_into(registry)` adds it to the reference's own `BACKENDS` so that
+`BackendSpec`, the `BACKENDS` dict and `get_backend(name)` with the same error text.  Entries: "hip"
+(this library) plus the reference's own "arrow" and "numpy" (lazy pass-throughs to pyarrow.compute / numpy,
+backends.py:27-48), so every `backend=` value the reference accepts keeps working.
+`register_into(registry)` adds "hip" to the reference's own `BACKENDS` so that
 `reference.stats(model, backend="hip")` works unchanged.
 """
 from __future__ import annotations
@@ -107,8 +109,20 @@ def _load_hip() -> Backend:
     return HipBackend()
 
 
+def _load_arrow() -> Backend:
+    from .backends_arrow import ArrowBackend      # lazy: pyarrow is imported only when asked for
+    return ArrowBackend()
+
+
+def _load_numpy() -> Backend:
+    from .backends_numpy import NumpyBackend
+    return NumpyBackend()
+
+
 BACKENDS: dict[str, BackendSpec] = {
     "hip": BackendSpec(name="hip", loader=_load_hip),
+    "arrow": BackendSpec(name="arrow", loader=_load_arrow),
+    "numpy": BackendSpec(name="numpy", loader=_load_numpy),
 }
 
 

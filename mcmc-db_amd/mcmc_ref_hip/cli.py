@@ -1,8 +1,10 @@
 """`mcmc-ref-hip` CLI: the hot-path commands of the reference's `mcmc-ref` CLI on the GPU.
 
-Mirrors src/mcmc_ref/cli.py for `list`, `stats`, `diagnostics`, `info`, `compare`, `convert` (same
-options, output formats and exit codes: compare exits 2 when the gate fails); `--backend` accepts
-"hip".  Provenance / pairs / draws-export commands are outside the statistics path and not included.
+Mirrors src/mcmc_ref/cli.py for `list`, `stats`, `diagnostics`, `info`, `compare`, `convert`,
+`provenance-generate` and `provenance-publish` (same options, echo strings and exit codes: compare exits 2 when the
+gate fails, provenance-generate exits 1 when any recipe failed); `--backend` accepts "hip" (default) and the
+reference's "arrow" / "numpy".  `provenance-scaffold` (Stan programs + data literals), pairs and draws-export
+commands are outside the statistics path and not included.
 """
 from __future__ import annotations
 
@@ -12,6 +14,7 @@ from pathlib import Path
 import click
 
 from . import convert as convert_mod
+from . import generate as generate_mod
 from . import reference
 from .store import DataStore
 
@@ -52,7 +55,7 @@ def list_cmd(format_: str) -> None:
 @click.argument("model")
 @click.option("--params", default=None, help="Comma-separated parameter list")
 @click.option("--format", "format_", type=click.Choice(["table", "csv", "json"], case_sensitive=False), default="table")
-@click.option("--backend", type=click.Choice(["hip"], case_sensitive=False), default="hip")
+@click.option("--backend", type=click.Choice(["hip", "arrow", "numpy"], case_sensitive=False), default="hip")
 @click.option("--quantile-mode", type=click.Choice(["exact"], case_sensitive=False), default="exact")
 @click.option("--include-diagnostics", is_flag=True, help="Include rhat/ess metrics")
 def stats_cmd(model, params, format_, backend, quantile_mode, include_diagnostics) -> None:
@@ -130,6 +133,37 @@ def convert_cmd(input_path: Path, name: str, force: bool) -> None:
     meta_dir.mkdir(parents=True, exist_ok=True)
     convert_mod.convert_file(input_path, name=name, out_draws_dir=draws_dir, out_meta_dir=meta_dir, force=force)
     click.echo(f"converted {name} -> {draws_dir}")
+
+
+@main.command("provenance-generate")
+@click.option("--scaffold-root", type=click.Path(path_type=Path), required=True)
+@click.option("--output-root", type=click.Path(path_type=Path), required=True)
+@click.option("--models", default=None, help="Optional comma-separated recipe names.")
+@click.option("--force", is_flag=True, help="Forward --force to convert quality checks.")
+@click.option("--fake-runner", is_flag=True, help="Use deterministic fake runner (testing only).")
+def provenance_generate_cmd(scaffold_root: Path, output_root: Path, models: str | None, force: bool,
+                            fake_runner: bool) -> None:
+    """Sampler archives -> draws/meta for every recipe of a scaffold (reference cli.py:248-274); the diagnostics of all
+    models run as one pipelined batch on the GPU."""
+    result = generate_mod.generate_reference_corpus(
+        scaffold_root=scaffold_root, output_root=output_root, models=models.split(",") if models else None,
+        force=force, runner=generate_mod.fake_jsonzip_runner if fake_runner else None)
+    click.echo(f"generated={result.generated} failed={result.failed} output={result.output_root}")
+    if result.errors:
+        for name, message in sorted(result.errors.items()):
+            click.echo(f"- {name}: {message}")
+        raise SystemExit(1)
+
+
+@main.command("provenance-publish")
+@click.option("--source-root", type=click.Path(path_type=Path), required=True)
+@click.option("--scaffold-root", type=click.Path(path_type=Path), required=True)
+@click.option("--package-root", type=click.Path(path_type=Path), required=True)
+def provenance_publish_cmd(source_root: Path, scaffold_root: Path, package_root: Path) -> None:
+    result = generate_mod.publish_reference_data(source_root=source_root, scaffold_root=scaffold_root,
+                                                 package_root=package_root)
+    click.echo(f"published draws={result.draws_copied} meta={result.meta_copied} pairs={result.pairs_copied} "
+               f"to={result.package_root}")
 
 
 if __name__ == "__main__":

@@ -2,7 +2,8 @@
 
 Mirrors src/mcmc_ref/compare.py:9-68: frozen dataclasses `ParamResult` / `CompareResult` with the
 same fields, `compare_stats` with the same failure strings, `compute_basic_stats` /
-`compute_stats_from_draws`.  The relative-error arithmetic and the moments run in libmcmcref_hip.
+`compute_stats_from_draws`.  The moments of the `actual` draws run in libmcmcref_hip; the O(P) relative-error
+arithmetic stays on the host unless there are enough pairs to be worth a launch (`mcr_compare`).
 """
 from __future__ import annotations
 
@@ -12,6 +13,9 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
+
+
+GPU_COMPARE_MIN_PAIRS = 4096      # below this many (ref, actual) pairs the gate is evaluated on the host
 
 
 @dataclass(frozen=True)
@@ -50,9 +54,12 @@ def compare_stats(
             refs.append(float(stats.get(metric, float("nan"))))
             acts.append(float(actual_stats[param].get(metric, float("nan"))))
     rel = ok = None
-    if refs:
+    if len(refs) >= GPU_COMPARE_MIN_PAIRS:
         ctx = context or _ffi.default_context()
         rel, ok = ctx.compare(refs, acts, float(tolerance))
+    elif refs:      # a handful of scalars: compare.py:41-43 as it stands (a launch + two copies would be pure latency)
+        rel = [abs(a - r) / max(abs(r), 1e-12) for r, a in zip(refs, acts)]
+        ok = [e <= tolerance for e in rel]
     for k, param, metric in order:
         if k < 0:
             failures.append(f"missing param: {param}")

@@ -146,7 +146,11 @@ class ConvertResult:
 
 
 def _read_json_zip(path: Path):
-    """Chain-list JSON-zip: [ {param: [draws...]}, ... ] (one dict per chain) -> long Arrow table."""
+    """Chain-list JSON-zip: [ {param: [draws...]}, ... ] (one dict per chain) -> long Arrow table.
+
+    As the reference builds it (convert.py:78-102): parameters in sorted order, `n_draws` taken from the first chain's
+    first parameter, longer chains cut at `n_draws`, a SHORTER chain is an IndexError, and a column keeps the type its
+    JSON numbers have (all-integer draws stay int64 in the written Parquet file, any float makes it double)."""
     import pyarrow as pa
     with zipfile.ZipFile(path) as zf:
         payload = json.loads(zf.read(zf.namelist()[0]))
@@ -158,8 +162,15 @@ def _read_json_zip(path: Path):
     cols = {"chain": np.repeat(np.arange(n_chains, dtype=np.int64), n_draws),
             "draw": np.tile(np.arange(n_draws, dtype=np.int64), n_chains)}
     for p in params:
-        cols[p] = np.concatenate([np.asarray(ch[p][:n_draws], dtype=np.float64) for ch in payload]) \
-            if n_draws else np.empty(0)
+        parts = []
+        for ch in payload:
+            if n_draws and len(ch[p]) < n_draws:
+                raise IndexError("list index out of range")
+            parts.append(np.asarray(ch[p][:n_draws]))
+        col = np.concatenate(parts) if n_draws else np.empty(0)
+        if col.dtype.kind not in "iuf":           # bools / None / strings: let pyarrow infer (and refuse) as it would
+            col = [v for part in parts for v in part.tolist()]
+        cols[p] = col
     return pa.table(cols)
 
 
@@ -189,24 +200,105 @@ def _ensure_chain_draw(table):
     return table.append_column("chain", chain).append_column("draw", draw)
 
 
+def convert_files(jobs, out_draws_dir: Path, out_meta_dir: Path, force: bool = False, source: str = "converted",
+                  context=None) -> list:
+    """`convert_file` for many inputs with the kernels pipelined: jobs = [(input_path, name), ...]; returns, per job,
+    a ConvertResult or the exception that `convert_file` would have raised for it (the per-recipe try/except of
+    generate.generate_reference_corpus, src/mcmc_ref/generate.py:77-96, becomes per-entry results).
+
+    All inputs are read and laid out first, the rectangular models are uploaded and enqueued with a rolling window of
+    MCR_MAX_INFLIGHT calls (consecutive models overlap on the context's lanes; a NaN draw or any other kernel-side
+    failure stays confined to its model), ragged models take the per-parameter route, then the quality gate and the
+    two files of every model are written."""
+    import pyarrow.parquet as pq
+    out_draws_dir, out_meta_dir = Path(out_draws_dir), Path(out_meta_dir)
+    min_chains = 1 if force else 4
+    n = len(jobs)
+    results: list = [None] * n
+    prepared: dict[int, tuple] = {}
+    for i, (input_path, _name) in enumerate(jobs):
+        try:
+            table = _ensure_chain_draw(_read_input(Path(input_path)))
+            params = [c for c in table.column_names if c not in {"chain", "draw"}]
+            n_chains, n_draws = _count_chains_draws(table)
+            x, counts = table_to_tensor(table, params)
+            if params and len(counts) < min_chains:
+                raise ValueError(f"R-hat diagnostics require at least {min_chains} chains; got {len(counts)} chain(s)")
+            prepared[i] = (table, params, n_chains, n_draws, x, counts)
+        except Exception as exc:  # noqa: BLE001 - reported per job
+            results[i] = exc
+    diags: dict[int, dict] = {}
+    ctx = None
+    if any(v[1] for v in prepared.values()):
+        ctx = context or _ffi.default_context()
+    window: list[tuple[int, object]] = []
+
+    def retire():
+        i, t = window.pop(0)
+        try:
+            r = ctx.wait_one().result()
+            diags[i] = {p: {"rhat": float(r["rhat"][k]), "ess_bulk": float(r["ess_bulk"][k]),
+                            "ess_tail": float(r["ess_tail"][k])} for k, p in enumerate(prepared[i][1])}
+        except _ffi.McrError as exc:
+            results[i] = ValueError(exc.message)
+        finally:
+            t.free()
+
+    ragged = []
+    for i, (table, params, n_chains, n_draws, x, counts) in prepared.items():
+        if not params:
+            diags[i] = {}
+            continue
+        if not np.all(counts == counts[0]):
+            ragged.append(i)
+            continue
+        if len(window) == _ffi.MCR_MAX_INFLIGHT:
+            retire()
+        try:
+            t = ctx.upload(x.reshape(len(params), len(counts), int(counts[0])), "pcn")
+            try:
+                ctx.enqueue(t, min_chains=min_chains, quantiles=())
+            except Exception:
+                t.free()
+                raise
+            window.append((i, t))
+        except _ffi.McrError as exc:
+            results[i] = ValueError(exc.message)
+    while window:
+        retire()
+    for i in ragged:                                  # chains of unequal length: one pipeline per parameter
+        table, params = prepared[i][:2]
+        try:
+            diags[i] = _compute_diagnostics(table, params, min_chains=min_chains, context=ctx)
+        except Exception as exc:  # noqa: BLE001
+            results[i] = exc
+    for i, (table, params, n_chains, n_draws, _x, _counts) in prepared.items():
+        if results[i] is not None:
+            continue
+        name = jobs[i][1]
+        try:
+            checks = _checks(n_chains, n_draws, diags[i])
+            if not force:
+                _enforce_checks(checks)
+            meta = {"model": name, "parameters": params, "n_chains": n_chains, "n_draws_per_chain": n_draws,
+                    "diagnostics": diags[i], "generated_date": date.today().isoformat(), "checks": checks,
+                    "source": source}
+            draws_path = out_draws_dir / f"{name}.draws.parquet"
+            meta_path = out_meta_dir / f"{name}.meta.json"
+            pq.write_table(table, draws_path)
+            meta_path.write_text(json.dumps(meta, indent=2, sort_keys=True))
+            results[i] = ConvertResult(draws_path=draws_path, meta_path=meta_path, meta=meta)
+        except Exception as exc:  # noqa: BLE001
+            results[i] = exc
+    return results
+
+
 def convert_file(input_path: Path, name: str, out_draws_dir: Path, out_meta_dir: Path, force: bool = False,
                  source: str = "converted") -> ConvertResult:
-    """Same contract as the reference's convert_file: diagnostics of every parameter (one GPU pipeline
-    per file), quality checks (raise ValueError("quality checks failed: ...") unless `force`), then
+    """Same contract as the reference's convert_file (convert.py:26-67): diagnostics of every parameter (one GPU
+    pipeline per file), quality checks (raise ValueError("quality checks failed: ...") unless `force`), then
     `<name>.draws.parquet` and `<name>.meta.json` (sorted keys, indent 2)."""
-    import pyarrow.parquet as pq
-    input_path, out_draws_dir, out_meta_dir = Path(input_path), Path(out_draws_dir), Path(out_meta_dir)
-    table = _ensure_chain_draw(_read_input(input_path))
-    params = [c for c in table.column_names if c not in {"chain", "draw"}]
-    n_chains, n_draws = _count_chains_draws(table)
-    diag = _compute_diagnostics(table, params, min_chains=1 if force else 4)
-    checks = _checks(n_chains, n_draws, diag)
-    if not force:
-        _enforce_checks(checks)
-    meta = {"model": name, "parameters": params, "n_chains": n_chains, "n_draws_per_chain": n_draws,
-            "diagnostics": diag, "generated_date": date.today().isoformat(), "checks": checks, "source": source}
-    draws_path = out_draws_dir / f"{name}.draws.parquet"
-    meta_path = out_meta_dir / f"{name}.meta.json"
-    pq.write_table(table, draws_path)
-    meta_path.write_text(json.dumps(meta, indent=2, sort_keys=True))
-    return ConvertResult(draws_path=draws_path, meta_path=meta_path, meta=meta)
+    res = convert_files([(input_path, name)], out_draws_dir, out_meta_dir, force=force, source=source)[0]
+    if isinstance(res, Exception):
+        raise res
+    return res

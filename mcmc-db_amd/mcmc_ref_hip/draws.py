@@ -24,12 +24,12 @@ class Draws:
         return self.data
 
     def to_numpy(self) -> Any:
-        """Rows x parameters (`(C*N, P)`, parameter index fastest): the array `np.stack(columns, axis=-1)` gives,
-        i.e. the "cnp" input layout of mcr_summarize after a reshape to (C, N, P)."""
-        from .backends import columns_to_matrix
+        """Rows x parameters (`(C*N, P)`, parameter index fastest): `np.stack(columns, axis=-1)` as the reference does
+        (draws.py:28-29), columns keeping their own dtypes (numpy promotes mixed ones); reshaped to (C, N, P) this is
+        the "cnp" input layout of mcr_summarize."""
         import numpy as np
-        matrix = columns_to_matrix(_materialise(self.data), self.params)      # [P][rows]
-        return np.ascontiguousarray(matrix.T)
+        table = _materialise(self.data)
+        return np.stack([table.column(p).to_numpy(zero_copy_only=False) for p in self.params], axis=-1)
 
     def to_list(self) -> list[dict[str, Any]]:
         table = _materialise(self.data)

@@ -71,8 +71,14 @@ def test_reference_stats_and_diagnostics(store):
     assert summ["mu"]["q50"] == rec["stats"]["numpy"]["mu"]["q50"]
     with pytest.raises(FileNotFoundError):
         reference.stats("nope", store=st)
-    with pytest.raises(ValueError, match="Unknown backend: arrow"):
-        reference.stats("eight", backend="arrow", store=st)
+    with pytest.raises(ValueError, match="Unknown backend: bogus"):
+        reference.stats("eight", backend="bogus", store=st)
+    # the reference's own backends stay selectable by name (reference.py:33,112 default to "arrow") and give exactly
+    # what the reference returned for this model
+    for b in ("arrow", "numpy"):
+        sb = reference.stats("eight", params=["mu", "tau"], backend=b, store=st)
+        assert sb == {p: rec["stats"][b][p] for p in ("mu", "tau")}, b
+    assert reference.compare("eight", {"mu": list(draws[params.index("mu")].reshape(-1))}, backend="arrow", store=st).passed
 
 
 def test_reference_draws_and_compare(store):
