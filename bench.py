@@ -10,13 +10,22 @@ R-hat, ESS bulk, ESS tail, truncation lags) over one synthetic model resident in
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (dominant
 kernel, HIP-event timed inside this process) and `cpu_baseline` (the C oracle on this host's cores).
-torch is imported only for N > 1 (rendezvous, barrier and the RCCL gather of the summaries).
+No torch anywhere: for N > 1 the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
+the launcher sets and talk through the library's RCCL communicator (mcmc_ref_hip.shard.Communicator:
+barrier, MAX-over-ranks clock, and the one all-gather of the per-parameter summary records).
+
+Workloads (--workload):
+  c1       BASELINE config 1, the headline: every rank its own 4 x 10000 x 100 f64 model (weak scaling)
+  c1split  ONE such model, its P axis cut into contiguous blocks over the ranks (strong scaling)
+  corpus   BASELINE configs 2/3: the 57 packaged model shapes, LPT-sharded over ranks (strong scaling)
+  stress   BASELINE config 4: 4 x 100000 x 10000 f32 (16 GB) generated on the device, P-split over ranks
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -27,6 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+TRAFFIC_FILE = ROOT / "profiles" / "pmc_traffic.json"      # rocprofv3 --pmc passes of tools/collect_profiles.sh
 
 # Algorithmic (compulsory) HBM bytes per param-draw and launch of each kernel, f64 input
 # (DESIGN.md "Kernels and rooflines").  Intermediate traffic a kernel causes
@@ -57,9 +67,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["c1", "corpus"], default="c1",
-                    help="c1 = BASELINE config 1 (default, the headline); corpus = configs 2/3: the 57 packaged "
-                         "model shapes (4.6 M param-draws), LPT-sharded over ranks (strong scaling)")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="the K-step timed window is repeated this many times; ms_per_step is the MEDIAN window "
+                         "(a 5 ms region is fragile: ramp-up and drain of the rolling window are ~10 %% of it)")
+    ap.add_argument("--workload", choices=["c1", "c1split", "corpus", "stress"], default="c1")
     ap.add_argument("--chains", type=int, default=4)
     ap.add_argument("--draws", type=int, default=10000)
     ap.add_argument("--params", type=int, default=100)
@@ -67,13 +78,11 @@ def parse_args():
                     help="pcn = Arrow column layout [P][C][N]; cnp = Draws.to_numpy layout [C][N][P]")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--inflight", type=int, default=8, help="steps enqueued before a host wait (1..8)")
-    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
-                    help="nccl = RCCL over xGMI (the real N > 1 runs); gloo = CPU rendezvous for rehearsing the "
-                         "N > 1 control flow with several ranks sharing one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
     ap.add_argument("--no-moments", action="store_true",
-                    help="skip the streaming-moments HBM roofline leg (4 GB f32 tensor generated on the device)")
+                    help="skip the streaming-moments HBM roofline leg (16 GB f32 tensor generated on the device)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the measured-HBM-peak probe")
     return ap.parse_args()
 
 
@@ -93,11 +102,63 @@ def validate(got: dict, exp: dict) -> tuple[bool, float]:
     return bool(ok and worst <= 1e-6), worst
 
 
-def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
+class Ranks:
+    """The ranks of this launch: RCCL communicator of the library for N > 1 (or MCR_BENCH_FORCE_DIST=1, which runs
+    every collective with a world of one so that the RCCL calls are exercised on a 1-GPU box)."""
+
+    def __init__(self, ctx, world: int, rank: int):
+        self.ctx, self.world, self.rank, self.comm = ctx, world, rank, None
+        if world > 1 or os.environ.get("MCR_BENCH_FORCE_DIST") == "1":
+            from mcmc_ref_hip import shard
+            self.comm = shard.Communicator(ctx, world, rank)
+
+    def barrier(self):
+        """Drains this rank's device work, then (N > 1) meets the other ranks."""
+        self.ctx.sync()
+        if self.comm is not None:
+            self.comm.barrier()
+
+    def max(self, x: float) -> float:
+        return float(self.comm.all_reduce([x], "max")[0]) if self.comm is not None else x
+
+    def all_true(self, flag: bool) -> bool:
+        return bool(self.comm.all_reduce([1.0 if flag else 0.0], "min")[0] > 0.5) if self.comm is not None else flag
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+
+
+def timed_windows(a, ranks: Ranks, run) -> tuple[float, list[float], object]:
+    """W warm-up steps, then `windows` timed regions of EXACTLY K steps each, every one bracketed by a barrier +
+    device sync on both sides and clocked as the MAX over ranks.  Returns (median seconds per window, all windows,
+    the last result handle of the last window)."""
+    run(a.warmup)
+    secs, last = [], None
+    for _ in range(max(1, a.windows)):
+        ranks.barrier()
+        t0 = time.perf_counter()
+        last = run(a.steps)
+        ranks.barrier()
+        secs.append(ranks.max(time.perf_counter() - t0))
+    return statistics.median(secs), secs, last
+
+
+def hbm_probe(ctx, a) -> dict | None:
+    if a.no_probe:
+        return None
+    try:
+        return ctx.hbm_probe(4 << 30, 5)
+    except Exception as exc:  # noqa: BLE001 - the probe is context for the roofline, never a reason to fail the bench
+        return {"error": str(exc)}
+
+
+def corpus_bench(a, ctx, ranks: Ranks):
     """BASELINE configs 2/3: one step = one pass over the whole 57-model corpus (shapes of the packaged
     reference set, synthetic draws), models LPT-sharded over ranks, same-shape models batched into one
-    kernel pipeline, one RCCL all_gather of 128-byte records at the end."""
-    from mcmc_ref_hip import corpus, shard
+    kernel pipeline, one RCCL all-gather of 128-byte records at the end."""
+    from mcmc_ref_hip import _ffi, corpus, shard
+    world, rank = ranks.world, ranks.rank
     models = corpus.synthetic_corpus(seed=4711)
     costs = [float(np.prod(m.shape)) for _, m in models]
     mine = shard.plan_shards(costs, world)[rank]
@@ -111,18 +172,8 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
         tensors.append((members, big, ctx.upload(big, "pcn")))
     total_pd = int(sum(costs))
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            if dist_dev == "cuda":
-                torch.cuda.synchronize()
-            dist.barrier()
-            if dist_dev == "cuda":
-                torch.cuda.synchronize()
-
     def run(steps):
         """Rolling window over (step, tensor group): the device never drains between corpus passes."""
-        from mcmc_ref_hip import _ffi
         last = None
         for _ in range(steps):
             cur = []
@@ -134,20 +185,11 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
         ctx.wait()
         return last
 
-    run(a.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    last = run(a.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, windows, last = timed_windows(a, ranks, run)
     recs = []
     valid = True
     from oracle import oracle as orc
-    for (members, big, t), bufs in zip(tensors, last):
+    for (members, big, t), bufs in zip(tensors, last or []):
         r = bufs.result()
         p0 = 0
         for i in members:
@@ -160,12 +202,8 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
             valid = valid and ok
         t.free()
     local = np.concatenate(recs) if recs else np.empty((0, shard.RECORD_DOUBLES))
-    allrec = shard.gather_records(local, dist, device=dist_dev, force=os.environ.get("MCR_BENCH_FORCE_DIST") == "1")
-    valid = valid and allrec.shape[0] == 460
-    if dist is not None:
-        flag = torch.tensor([1.0 if valid else 0.0], device=dist_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        valid = bool(flag.item() > 0.5)
+    allrec = shard.gather_records(local, ranks.comm)
+    valid = ranks.all_true(valid and allrec.shape[0] == 460)
     if rank == 0:
         value = a.steps * total_pd / elapsed
         print(json.dumps({
@@ -175,12 +213,96 @@ def corpus_bench(a, ctx, world, rank, dist, torch, dist_dev=None):
             "config": {"workload": "packaged mcmc-ref-data corpus shapes: 57 models, 460 params, 4.6 M param-draws "
                                    "(BASELINE configs 2/3), synthetic draws", "layout": "pcn",
                        "sharding": f"whole models, greedy LPT over {world} rank(s), same-shape models batched, "
-                                   "one all_gather of 128-byte records"},
-            "validated": valid, "pipeline_alg_GBps": value * 8 / 1e9}), flush=True)
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+                                   "one RCCL all-gather of 128-byte records"},
+            "validated": valid, "pipeline_alg_GBps": value * 8 / 1e9,
+            "ms_per_step_windows": [s / a.steps * 1e3 for s in windows]}), flush=True)
     return 0 if valid else 1
+
+
+def split_bench(a, ctx, ranks: Ranks):
+    """ONE model, its parameter axis cut into contiguous blocks over the ranks (strong scaling).
+    c1split: the C1 model (host-generated, validated against the oracle on every rank's block).
+    stress : BASELINE config 4, 4 x 100000 x 10000 f32 = 16 GB, generated on the device block by block; validated by
+             size-independent properties over ALL parameters of the block + the oracle on 16 parameters."""
+    from mcmc_ref_hip import shard, synth
+    world, rank = ranks.world, ranks.rank
+    stress = a.workload == "stress"
+    C, N, P = (4, 100000, 10000) if stress else (a.chains, a.draws, a.params)
+    dt = np.float32 if stress else (np.float64 if a.dtype == "f64" else np.float32)
+    p0, p1 = shard.param_block(P, world, rank)
+    pb = p1 - p0
+    host = None
+    if stress:
+        t = ctx.alloc_tensor(C, N, max(pb, 1), dt)
+        if pb:
+            ctx.fill_synthetic(t, 4711, p0=p0)
+    else:
+        host = synth.c1_model(C, N, P, seed=4711, params=range(p0, p1), dtype=dt)
+        t = ctx.upload(host if pb else np.zeros((1, C, N), dtype=dt), "pcn")
+    def run(steps):
+        last = None
+        for _ in range(steps):
+            if ctx.inflight >= (1 if stress else 8):
+                ctx.wait_one()
+            last = ctx.enqueue(t) if pb else None
+        ctx.wait()
+        return last
+
+    elapsed, windows, last = timed_windows(a, ranks, run)
+    valid, worst, checked = True, 0.0, "nothing"
+    recs = np.empty((0, shard.RECORD_DOUBLES))
+    if pb:
+        got = last.result()
+        recs = shard.pack_records(got, 0, C, N, param0=p0)
+        if not a.no_validate:
+            from oracle import oracle as orc
+            if stress:
+                p = np.arange(p0, p1)
+                sig = 10.0 ** ((p % 7) - 3)
+                M = C * N
+                valid = bool(np.all(np.abs(got["mean"] - p) < 0.02 * sig) and np.all(np.abs(got["std"] / sig - 1) < 0.02)
+                             and np.all(got["q"][:, 0] <= got["q"][:, 1]) and np.all(got["q"][:, 1] <= got["q"][:, 2])
+                             and np.array_equal(got["q"][:, 1], got["median"])
+                             and np.all((got["ess_bulk"] > 0) & (got["ess_bulk"] <= M)) and np.all((got["ess_tail"] > 0) & (got["ess_tail"] <= M))
+                             and np.all(got["rhat"] >= got["rhat_bulk"]) and np.all(got["rhat"] < 1.01)
+                             and np.all(got["lag_bulk"] >= 0) and np.all(got["lag_tail"] >= 0))
+                sel = np.unique(np.linspace(0, pb - 1, 16).astype(int))
+                sub = np.stack([ctx_row(ctx, t, int(i), M) for i in sel])      # 16 rows of the block, not the block
+                ok, worst = validate({k: (v[sel] if k != "q_lo" else v) for k, v in got.items()},
+                                     orc.summarize(sub.reshape(len(sel), C, N), "pcn"))
+                valid = valid and ok
+                checked = f"properties over all {pb} parameters of the block + oracle on {len(sel)}"
+            else:
+                valid, worst = validate(got, orc.summarize(host, "pcn"))
+                checked = f"oracle on all {pb} parameters of the block"
+    allrec = shard.gather_records(recs, ranks.comm)
+    valid = ranks.all_true(valid and allrec.shape[0] == P and
+                           np.array_equal(allrec[:, shard.RECORD_FIELDS.index("param_idx")], np.arange(P)))
+    if rank == 0:
+        value = a.steps * C * N * P / elapsed
+        es = np.dtype(dt).itemsize
+        print(json.dumps({
+            "metric": "validated param-draws/sec", "value": value if valid else 0.0, "unit": "param-draws/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if es == 4 else "f64",
+            "data": "synthetic",
+            "config": {"workload": (f"stress: {C}x{N}x{P} f32 (16 GB) generated on the device (BASELINE config 4)" if stress else
+                                    f"one {C}x{N}x{P} model (C1)") + f", parameter axis split over {world} rank(s)",
+                       "layout": "pcn", "sharding": "contiguous parameter blocks, no halo, one RCCL all-gather of records"},
+            "validated": valid, "max_rel_err": worst, "validation": checked,
+            "pipeline_alg_GBps": value * es / 1e9, "pipeline_frac_of_hbm": value * es / 1e9 / HBM_PEAK_GBS / world,
+            "ms_per_step_windows": [s / a.steps * 1e3 for s in windows]}), flush=True)
+    t.free()
+    return 0 if valid else 1
+
+
+def ctx_row(ctx, t, i: int, M: int) -> np.ndarray:
+    """Row i (M f32 draws) of a device tensor, without pulling the whole block to the host."""
+    import ctypes as C
+    out = np.empty(M, dtype=np.float32)
+    ctx._check(ctx.lib.mcr_memcpy_d2h(ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(t.buf.ptr.value + i * M * 4),
+                                      out.nbytes))
+    return out
 
 
 def main():
@@ -190,27 +312,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    dist = torch = None
-    dist_dev = None
-    # MCR_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so that the RCCL calls of the
-    # N > 1 path (barrier, all_reduce, all_gather_into_tensor on device tensors) can be exercised on a 1-GPU box.
-    force_dist = os.environ.get("MCR_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        if a.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            dist_dev = "cuda"
-        else:   # rehearsal: ranks may share a GPU, collectives run on CPU tensors
-            dist.init_process_group("gloo")
-            dist_dev = "cpu"
 
     from mcmc_ref_hip import _ffi, synth
     ndev = max(_ffi.load_library().mcr_device_count(), 1)
-    ctx = _ffi.Context(local_rank % ndev if a.dist_backend == "gloo" else local_rank)
-    if a.workload == "corpus":
-        return corpus_bench(a, ctx, world, rank, dist, torch, dist_dev)
+    ctx = _ffi.Context(local_rank % ndev)
+    ranks = Ranks(ctx, world, rank)
+    try:
+        if a.workload == "corpus":
+            return corpus_bench(a, ctx, ranks)
+        if a.workload in ("c1split", "stress"):
+            return split_bench(a, ctx, ranks)
+        return c1_bench(a, ctx, ranks, _ffi, synth)
+    finally:
+        ranks.close()
+        ctx.close()
+
+
+def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
+    world, rank = ranks.world, ranks.rank
     C, N, P = a.chains, a.draws, a.params
     dt = np.float64 if a.dtype == "f64" else np.float32
     # independent models shard across ranks: rank r validates its own model (weak scaling)
@@ -218,15 +337,6 @@ def main():
     host = x if a.layout == "pcn" else np.ascontiguousarray(np.transpose(x, (1, 2, 0)))
     t = ctx.upload(host, a.layout)
     inflight = max(1, min(a.inflight, _ffi.MCR_MAX_INFLIGHT))
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            if dist_dev == "cuda":
-                torch.cuda.synchronize()
-            dist.barrier()
-            if dist_dev == "cuda":
-                torch.cuda.synchronize()
 
     def run(steps):
         """Rolling window: at most `inflight` steps outstanding, the device never drains in between."""
@@ -238,13 +348,8 @@ def main():
         ctx.wait()
         return last
 
-    run(a.warmup)
-    # ---- timed region: exactly K steps (rolling window of up to `inflight` calls over the context's lanes) ----
-    barrier()
-    t0 = time.perf_counter()
-    last = run(a.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: windows of exactly K steps (rolling window of up to `inflight` calls over the lanes) ----
+    elapsed, windows, last = timed_windows(a, ranks, run)
     # ---- same K steps again with a HIP event pair around every kernel launch (per-kernel roofline).
     #      With several lanes the kernels of consecutive steps overlap, which would inflate every
     #      per-kernel duration: this pass runs on a single-lane
@@ -269,18 +374,14 @@ def main():
     ctx1.close()
     os.environ.pop("MCR_LANES", None)
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     got = last.result()
 
     # final summary gather over RCCL: fixed-size (128 B) per-parameter records to every rank
     gathered_ok = True
-    if dist is not None:
+    if ranks.comm is not None:
         from mcmc_ref_hip import shard
         mine = shard.pack_records(got, rank, C, N)
-        allrec = shard.gather_records(mine, dist, device=dist_dev, force=force_dist)
+        allrec = shard.gather_records(mine, ranks.comm)
         sel = allrec[allrec[:, shard.RECORD_FIELDS.index("model_idx")] == rank]
         gathered_ok = allrec.shape[0] == world * P and np.array_equal(sel, mine, equal_nan=True)
 
@@ -327,17 +428,21 @@ def main():
                         npass += 1
                 cpu["numpy_path"] = {"value": npass * C * N * P / nsec, "unit": "param-draws/s", "cores": T,
                                      "sample": f"{npass} passes of oracle/numpy_path.py over {T} threads ({nsec:.1f} s)"}
-    if dist is not None:
-        flag = torch.tensor([1.0 if (valid and gathered_ok) else 0.0], device=dist_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        valid = bool(flag.item() > 0.5)
+    valid = ranks.all_true(valid and gathered_ok)
+
+    probe = hbm_probe(ctx, a) if rank == 0 else None
+    peak_measured = probe.get("read_GBps") if probe and "error" not in probe else None
 
     moments = None
     if rank == 0 and not a.no_moments:
-        # BASELINE config 4 shape, quarter size: 4 x 100000 x 2500 f32 = 4 GB, generated on the device.
+        # BASELINE config 4 itself: 4 x 100000 x 10000 f32 = 16 GB, generated on the device.
         # One HBM pass per launch; algorithmic bytes = 4 B per param-draw.
-        mc, mn, mp = 4, 100000, 2500
-        big = ctx.alloc_tensor(mc, mn, mp, np.float32)
+        mc, mn, mp = 4, 100000, 10000
+        try:
+            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
+        except _ffi.McrError:                      # a smaller device: quarter-size tensor
+            mp = 2500
+            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
         ctx.fill_synthetic(big, 4711)
         ctx.moments(big)
         ctx.profile(True)
@@ -351,10 +456,14 @@ def main():
         sig = 10.0 ** ((np.arange(mp) % 7) - 3)
         ok_m = bool(np.max(np.abs(mm - np.arange(mp)) / sig) < 0.05 and np.max(np.abs(ms / sig - 1)) < 0.05)
         gbs = mc * mn * mp * 4 / (kms * 1e-3) / 1e9
-        moments = {"kernel": "k_moments_rows<float>", "workload": f"{mc}x{mn}x{mp} f32 (4 GB) synthetic, on-device",
-                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        moments = {"kernel": "k_moments_rows<float>", "workload": f"{mc}x{mn}x{mp} f32 ({mc * mn * mp * 4 / 1e9:.0f} GB) synthetic, on-device",
+                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s",
+                   "frac": gbs / HBM_PEAK_GBS, "frac_of_measured": (gbs / peak_measured) if peak_measured else None,
                    "avg_launch_us": kms * 1e3, "param_draws_per_s": mc * mn * mp / (kms * 1e-3), "sane": ok_m,
-                   "traffic": 4000428032}   # 2*FETCH_SIZE (profiles/r01_pmc_fetch_moments_4GB.csv), writes ~1 MB
+                   "traffic": None, "traffic_source": None}
+        tr = traffic_table().get("moments-4x100000x2500-f32")
+        if tr is not None and mp == 2500:
+            moments["traffic"], moments["traffic_source"] = tr.get("k_moments"), str(TRAFFIC_FILE.relative_to(ROOT))
 
     if rank == 0:
         pd_step = C * N * P
@@ -370,13 +479,7 @@ def main():
                 dom, dom_ms = name, r["total_ms"]
         dom_avg_s = prof[dom]["total_ms"] / prof[dom]["launches"] * 1e-3
         dom_alg = alg_bytes(dom, es) * pd_step
-        traffic = None
-        tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists():
-            try:
-                traffic = json.loads(tf.read_text()).get(f"{C}x{N}x{P}-{a.dtype}-{a.layout}", {}).get(dom)
-            except Exception:
-                traffic = None
+        traffic = traffic_table().get(f"{C}x{N}x{P}-{a.dtype}-{a.layout}", {}).get(dom)
         achieved = dom_alg / dom_avg_s / 1e9
         value = world * a.steps * pd_step / elapsed
         out = {
@@ -387,24 +490,37 @@ def main():
             "config": {"workload": f"single posteriordb-shaped model, {C}x{N}x{P} synthetic draws per GPU "
                                    "(BASELINE config 1; AR(1) chains, ties and a shifted chain; SURVEY 8(d) C1)",
                        "layout": a.layout, "statistics": "mean,std,q5,q50,q95,split_rhat,ess_bulk,ess_tail",
-                       "sharding": f"independent models, {world} rank(s), RCCL all_gather of summaries"},
+                       "sharding": f"independent models, {world} rank(s), RCCL all-gather of summaries (library, no torch)"},
             "validated": valid, "max_rel_err": worst,
+            "timing": f"median of {len(windows)} windows of {a.steps} steps, each bracketed by barrier + device sync, MAX over ranks",
+            "ms_per_step_windows": [round(s / a.steps * 1e3, 5) for s in windows],
             "ms_per_step_event_pass": elapsed_prof / a.steps * 1e3,
             "pipeline_alg_GBps": value / world * es / 1e9,
             "pipeline_frac_of_hbm": value / world * es / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "peak_measured": peak_measured, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
+                         "traffic": traffic,
+                         "traffic_source": (str(TRAFFIC_FILE.relative_to(ROOT)) + " (rocprofv3 --pmc passes of an earlier run of this "
+                                            "configuration, not counters of this run)") if traffic is not None else None,
                          "avg_launch_us": dom_avg_s * 1e6, "alg_bytes_per_launch": dom_alg},
+            "hbm_probe": probe,
             "kernels": kern,
             "moments_roofline": moments,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     t.free()
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
     return 0 if valid else 1
+
+
+def traffic_table() -> dict:
+    if not TRAFFIC_FILE.exists():
+        return {}
+    try:
+        return json.loads(TRAFFIC_FILE.read_text())
+    except Exception:  # noqa: BLE001
+        return {}
 
 
 if __name__ == "__main__":

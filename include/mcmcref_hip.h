@@ -201,6 +201,40 @@ int mcr_profile_get(mcr_ctx* ctx, mcr_kernel_time* out, int max, int* n);
 int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P,
                        uint64_t seed);
 
+/* What this device's HBM delivers, measured: best of `iters` passes of a read-only streaming kernel over `bytes`
+ * (read_gbps) and of a device-to-device copy (copy_gbps = bytes read + written per second); either may be NULL.
+ * bench.py prints it as `peak_measured` beside the 8 TB/s specification peak. */
+int mcr_hbm_probe(mcr_ctx* ctx, size_t bytes, int iters, double* read_gbps, double* copy_gbps);
+/* The same for the parameter block [p0, p0 + P) of that tensor: draws_dev receives P * C * N elements that equal the
+ * corresponding slice of the whole tensor (a rank of a P-split model generates only its own columns). */
+int mcr_fill_synthetic_at(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t p0,
+                          uint64_t seed);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, models / parameter blocks sharded with no data-path
+ * exchange, and ONE collective at the end -- an RCCL all-gather of fixed-size per-parameter summary
+ * records over xGMI.  The reference has no counterpart (it is single-process); this replaces the loop
+ * over models of generate.generate_reference_corpus (src/mcmc_ref/generate.py:77-96) being run on N
+ * devices.  librccl is loaded on first use (dlopen); failures return MCR_ECOMM.
+ * Ranks must agree on a 128-byte id: rank 0 calls mcr_comm_unique_id and hands the bytes to the others
+ * by any means (mcmc_ref_hip.shard uses a file keyed on MASTER_ADDR / MASTER_PORT), then every rank
+ * calls mcr_comm_init (collective).  All buffers are host pointers; calls are synchronous.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mcr_comm mcr_comm;
+#define MCR_COMM_ID_BYTES 128
+#define MCR_RECORD_DOUBLES 16 /* one per-parameter summary record = 128 bytes */
+int mcr_comm_unique_id(void* id, size_t len);
+int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** out);
+void mcr_comm_free(mcr_comm* comm);
+int mcr_comm_world(const mcr_comm* comm);
+int mcr_comm_rank(const mcr_comm* comm);
+/* ncclAllGather: every rank sends `count` doubles and receives world * count doubles in rank order. */
+int mcr_comm_all_gather(mcr_comm* comm, const double* send, int64_t count, double* recv);
+/* ncclAllReduce in place over n doubles; op: 0 = sum, 1 = max, 2 = min (max-over-ranks clock, all-valid flag). */
+int mcr_comm_all_reduce(mcr_comm* comm, double* vals, int64_t n, int op);
+/* Drains this context's lanes, then synchronises the ranks. */
+int mcr_comm_barrier(mcr_comm* comm);
+
 /* ------------------------------------------------------------------------------------------------
  * Parquet ingest: draws file -> device tensor.
  * Replaces pq.read_table / pq.ParquetFile + to_numpy on the way into the statistics

@@ -26,6 +26,7 @@
 #include "mcr_diag.hpp"
 #include "mcr_ext.hpp"
 #include "mcr_parquet.hpp"
+#include "mcr_comm.hpp"
 
 using namespace mcr;
 
@@ -1301,26 +1302,203 @@ int mcr_profile_get(mcr_ctx* ctx, mcr_kernel_time* out, int max, int* n)
     return MCR_OK;
 }
 
-int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, uint64_t seed)
+int mcr_hbm_probe(mcr_ctx* ctx, size_t bytes, int iters, double* read_gbps, double* copy_gbps)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (bytes < ((size_t)1 << 20) || iters < 1 || (!read_gbps && !copy_gbps)) return fail(ctx, MCR_EINVAL, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bytes &= ~(size_t)4095;
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(ctx, hipMalloc(&a, bytes));
+    if (hipMalloc(&b, copy_gbps ? bytes : 4096 * 4) != hipSuccess) { hipFree(a); return fail(ctx, MCR_ENOMEM, "probe buffer"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipStream_t st = ctx->stream;
+    int rc = MCR_OK;
+    auto best_of = [&](auto&& launch) -> double {
+        float best = 1e30f;
+        launch();                                                  // warm-up (page faults, clocks)
+        for (int k = 0; k < iters; ++k) {
+            hipEventRecord(e0, st); launch(); hipEventRecord(e1, st);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f && ms < best) best = ms;
+        }
+        return (double)best;
+    };
+    if (hipMemsetAsync(a, 0x5A, bytes, st) != hipSuccess) rc = fail(ctx, MCR_EHIP, "memset failed");
+    if (!rc && read_gbps) {
+        const i64 nvec = (i64)(bytes / 16);
+        const double ms = best_of([&] { hipLaunchKernelGGL(k_stream_read, dim3(256 * 16), dim3(256), 0, st, (const uint4*)a, nvec, (u32*)b); });
+        *read_gbps = (double)bytes / (ms * 1e-3) / 1e9;
+    }
+    if (!rc && copy_gbps) {
+        const double ms = best_of([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st); });
+        *copy_gbps = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;     // bytes read + bytes written
+    }
+    hipStreamSynchronize(st);
+    if (hipGetLastError() != hipSuccess && !rc) rc = fail(ctx, MCR_EHIP, "probe launch failed");
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    return rc;
+}
+
+int mcr_fill_synthetic_at(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, int64_t p0, uint64_t seed)
 {
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
     if (dtype != MCR_F64 && dtype != MCR_F32) return fail(ctx, MCR_EINVAL, "unsupported dtype %d", dtype);
+    if (C < 0 || N < 0 || P < 0 || p0 < 0) return fail(ctx, MCR_EINVAL, "negative dimension");
     const i64 total = C * N * P;
     if (total <= 0) return MCR_OK;
     if (!draws_dev) return fail(ctx, MCR_EINVAL, "draws is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     i64 blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
+    const i64 first = p0 * C * N;       // element index of the block's first draw in the whole tensor
     if (dtype == MCR_F64) {
         LAUNCH(ctx, K_FILL, (k_fill_synth<double>), dim3((unsigned)blocks), dim3(256), 0, (double*)draws_dev, total,
-               (i64)(C * N), (u64)seed);
+               (i64)(C * N), (u64)seed, first);
     } else {
         LAUNCH(ctx, K_FILL, (k_fill_synth<float>), dim3((unsigned)blocks), dim3(256), 0, (float*)draws_dev, total,
-               (i64)(C * N), (u64)seed);
+               (i64)(C * N), (u64)seed, first);
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     prof_resolve(ctx);
     return MCR_OK;
+}
+
+int mcr_fill_synthetic(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, int64_t N, int64_t P, uint64_t seed)
+{
+    return mcr_fill_synthetic_at(ctx, draws_dev, dtype, C, N, P, 0, seed);
+}
+
+
+// ---- multi-GPU: the RCCL communicator -------------------------------------------------------------
+
+struct mcr_comm {
+    mcr_ctx* ctx = nullptr;
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;
+    int world = 1, rank = 0;
+    void* dbuf = nullptr; size_t dbytes = 0;      // device staging (send block + receive blocks)
+};
+
+namespace {
+int comm_fail(mcr_ctx* ctx, const char* what, ncclResult_t r)
+{
+    mcr::comm::Api* a = mcr::comm::api();
+    return fail(ctx, MCR_ECOMM, "%s failed: %s", what, (a && a->GetErrorString) ? a->GetErrorString(r) : "RCCL error");
+}
+int comm_buf(mcr_comm* c, size_t bytes)
+{
+    if (bytes <= c->dbytes) return MCR_OK;
+    if (c->dbuf) { hipFree(c->dbuf); c->dbuf = nullptr; c->dbytes = 0; }
+    HIP_TRY(c->ctx, hipMalloc(&c->dbuf, bytes));
+    c->dbytes = bytes;
+    return MCR_OK;
+}
+}  // namespace
+
+int mcr_comm_unique_id(void* id, size_t len)
+{
+    if (!id || len < MCR_COMM_ID_BYTES) return fail(nullptr, MCR_EINVAL, "id buffer must hold %d bytes", MCR_COMM_ID_BYTES);
+    mcr::comm::Api* a = mcr::comm::api();
+    if (!a) return fail(nullptr, MCR_ECOMM, "librccl could not be loaded: %s", mcr::comm::api_why());
+    static_assert(sizeof(ncclUniqueId) == MCR_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId uid;
+    const ncclResult_t r = a->GetUniqueId(&uid);
+    if (r != ncclSuccess) return comm_fail(nullptr, "ncclGetUniqueId", r);
+    memcpy(id, &uid, sizeof uid);
+    return MCR_OK;
+}
+
+int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** out)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(ctx, MCR_EINVAL, "bad communicator arguments (world %d, rank %d)", world, rank);
+    *out = nullptr;
+    mcr::comm::Api* a = mcr::comm::api();
+    if (!a) return fail(ctx, MCR_ECOMM, "librccl could not be loaded: %s", mcr::comm::api_why());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mcr_comm* c = new (std::nothrow) mcr_comm();
+    if (!c) return fail(ctx, MCR_ENOMEM, "out of host memory");
+    c->ctx = ctx; c->world = world; c->rank = rank;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(ctx, MCR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    const ncclResult_t r = a->CommInitRank(&c->nccl, world, uid, rank);      // collective: every rank of the world calls it
+    if (r != ncclSuccess) { hipStreamDestroy(c->stream); delete c; return comm_fail(ctx, "ncclCommInitRank", r); }
+    *out = c;
+    return MCR_OK;
+}
+
+void mcr_comm_free(mcr_comm* c)
+{
+    if (!c) return;
+    hipSetDevice(c->ctx->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    mcr::comm::Api* a = mcr::comm::api();
+    if (a && c->nccl) a->CommDestroy(c->nccl);
+    if (c->dbuf) hipFree(c->dbuf);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mcr_comm_world(const mcr_comm* c) { return c ? c->world : -1; }
+int mcr_comm_rank(const mcr_comm* c) { return c ? c->rank : -1; }
+
+// THE collective of the path: every rank contributes `count` doubles, every rank receives world * count doubles in
+// rank order (ncclAllGather over xGMI).  Host pointers; staged through a small device buffer on the communicator's stream.
+int mcr_comm_all_gather(mcr_comm* c, const double* send, int64_t count, double* recv)
+{
+    if (!c) return fail(nullptr, MCR_EINVAL, "comm is NULL");
+    mcr_ctx* ctx = c->ctx;
+    if (count < 0 || (count > 0 && (!send || !recv))) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (count == 0) return MCR_OK;
+    mcr::comm::Api* a = mcr::comm::api();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t sb = (size_t)count * 8, rb = sb * (size_t)c->world;
+    int rc = comm_buf(c, align_up(sb, 256) + rb);
+    if (rc) return rc;
+    char* d_send = (char*)c->dbuf;
+    char* d_recv = d_send + align_up(sb, 256);
+    HIP_TRY(ctx, hipMemcpyAsync(d_send, send, sb, hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t r = a->AllGather(d_send, d_recv, (size_t)count, ncclDouble, c->nccl, c->stream);
+    if (r != ncclSuccess) return comm_fail(ctx, "ncclAllGather", r);
+    HIP_TRY(ctx, hipMemcpyAsync(recv, d_recv, rb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+    return MCR_OK;
+}
+
+// Element-wise reduction of n host doubles over the ranks, in place (op: 0 sum, 1 max, 2 min): the bench's
+// max-over-ranks clock and "every rank validated" flag, and (n = 1) a barrier.
+int mcr_comm_all_reduce(mcr_comm* c, double* vals, int64_t n, int op)
+{
+    if (!c) return fail(nullptr, MCR_EINVAL, "comm is NULL");
+    mcr_ctx* ctx = c->ctx;
+    if (n < 0 || (n > 0 && !vals) || op < 0 || op > 2) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (n == 0) return MCR_OK;
+    mcr::comm::Api* a = mcr::comm::api();
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t b = (size_t)n * 8;
+    int rc = comm_buf(c, b);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(c->dbuf, vals, b, hipMemcpyHostToDevice, c->stream));
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    const ncclResult_t r = a->AllReduce(c->dbuf, c->dbuf, (size_t)n, ncclDouble, ops[op], c->nccl, c->stream);
+    if (r != ncclSuccess) return comm_fail(ctx, "ncclAllReduce", r);
+    HIP_TRY(ctx, hipMemcpyAsync(vals, c->dbuf, b, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+    return MCR_OK;
+}
+
+int mcr_comm_barrier(mcr_comm* c)
+{
+    if (!c) return fail(nullptr, MCR_EINVAL, "comm is NULL");
+    for (hipStream_t st : c->ctx->lane_stream) if (st) HIP_TRY(c->ctx, hipStreamSynchronize(st));
+    double one = 1.0;
+    return mcr_comm_all_reduce(c, &one, 1, 0);
 }
 
 

@@ -973,12 +973,33 @@ __global__ void k_compare(const double* __restrict__ ref, const double* __restri
     pass[i] = (e <= tol) ? 1 : 0;
 }
 
-// Synthetic stress tensor (SURVEY.md 8(d) C4): iid N(p, sigma_p), counter-based, layout [P][C][N].
-template <typename T>
-__global__ __launch_bounds__(256) void k_fill_synth(T* __restrict__ out, i64 total, i64 M, u64 seed)
+// Read-only streaming probe: what the HBM delivers to a kernel that does nothing but 16-byte loads (8 in flight per
+// lane).  bench.py reports it as `peak_measured` next to the 8 TB/s specification peak.
+__global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ src, i64 nvec, u32* __restrict__ sink)
 {
     const i64 stride = (i64)gridDim.x * 256;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    u32 acc = 0;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+        uint4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
+    }
+    for (; i < nvec; i += stride) { const uint4 r = src[i]; acc ^= r.x ^ r.y ^ r.z ^ r.w; }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;      // practically never: keeps the loads alive without a store stream
+}
+
+// Synthetic stress tensor (SURVEY.md 8(d) C4): iid N(p, sigma_p), counter-based, layout [P][C][N].
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_synth(T* __restrict__ out, i64 total, i64 M, u64 seed, i64 first)
+{
+    // `first` = index of out[0] in the whole tensor: a rank that holds a parameter block of a P-split model
+    //  generates exactly its slice of the one global tensor.
+    const i64 stride = (i64)gridDim.x * 256;
+    for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < total; j += stride) {
+        const i64 i = first + j;
         const i64 p = i / M;
         const u64 base = seed * 0x9E3779B97F4A7C15ull + 2ull * (u64)i;
         const u64 h1 = splitmix64(base), h2 = splitmix64(base + 1);
@@ -989,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_fill_synth(T* __restrict__ out, i64 tot
         double sigma = 1.0;
         for (; k > 0; --k) sigma *= 10.0;
         for (; k < 0; ++k) sigma /= 10.0;
-        out[i] = (T)((double)p + sigma * e);
+        out[j] = (T)((double)p + sigma * e);
     }
 }
 

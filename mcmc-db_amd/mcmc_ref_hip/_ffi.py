@@ -94,6 +94,16 @@ SYMBOLS = {
     "mcr_profile_reset": (C.c_int, [C.c_void_p]),
     "mcr_profile_get": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),
     "mcr_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _I64, _I64, C.c_uint64]),
+    "mcr_fill_synthetic_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _I64, _I64, _I64, _I64, C.c_uint64]),
+    "mcr_hbm_probe": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, _dp, _dp]),
+    "mcr_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mcr_comm_free": (None, [C.c_void_p]),
+    "mcr_comm_world": (C.c_int, [C.c_void_p]),
+    "mcr_comm_rank": (C.c_int, [C.c_void_p]),
+    "mcr_comm_all_gather": (C.c_int, [C.c_void_p, _dp, _I64, _dp]),
+    "mcr_comm_all_reduce": (C.c_int, [C.c_void_p, _dp, _I64, C.c_int]),
+    "mcr_comm_barrier": (C.c_int, [C.c_void_p]),
     "mcr_parquet_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mcr_parquet_close": (None, [C.c_void_p]),
     "mcr_parquet_num_rows": (C.c_int64, [C.c_void_p]),
@@ -294,9 +304,16 @@ class Context:
         code = MCR_F64 if np.dtype(dtype) == np.float64 else MCR_F32
         return DeviceTensor(self, buf, (code, C_, N, P, N, 1, C_ * N))
 
-    def fill_synthetic(self, t: DeviceTensor, seed: int = 4711):
+    def fill_synthetic(self, t: DeviceTensor, seed: int = 4711, p0: int = 0):
+        """Synthetic stress draws; p0 > 0: `t` is the parameter block [p0, p0 + P) of a larger tensor."""
         code, C_, N, P = t.targs[:4]
-        self._check(self.lib.mcr_fill_synthetic(self.handle, t.buf.ptr, code, C_, N, P, seed))
+        self._check(self.lib.mcr_fill_synthetic_at(self.handle, t.buf.ptr, code, C_, N, P, int(p0), seed))
+
+    def hbm_probe(self, nbytes: int = 4 << 30, iters: int = 5) -> dict:
+        """Measured HBM rates of this device (GB/s): read-only streaming kernel and device-to-device copy."""
+        rd, cp = C.c_double(0.0), C.c_double(0.0)
+        self._check(self.lib.mcr_hbm_probe(self.handle, int(nbytes), int(iters), C.byref(rd), C.byref(cp)))
+        return {"read_GBps": rd.value, "copy_GBps": cp.value}
 
     def sync(self):
         self._check(self.lib.mcr_sync(self.handle))

@@ -1,7 +1,9 @@
-"""The N > 1 code path of bench.py over RCCL, exercised on one GPU: a one-rank process group launched exactly as
-the driver launches N ranks (`python -m torch.distributed.run ...`), with MCR_BENCH_FORCE_DIST=1 so that the
-barrier, the MAX all_reduce of the timing and the all_gather of the 128-byte records really go through
-backend "nccl" (= RCCL) on device tensors.  World sizes > 1 are covered with gloo in tests/test_host_cpu.py."""
+"""The N > 1 code path of bench.py over RCCL, exercised on one GPU: one rank launched exactly as the driver launches
+N ranks (`python -m torch.distributed.run ...`; torch lives in the launcher only, bench.py imports none), with
+MCR_BENCH_FORCE_DIST=1 so that the unique-id hand-over, ncclCommInitRank, the barrier, the MAX all-reduce of the
+clock and the all-gather of the 128-byte records really go through librccl inside libmcmcref_hip
+(mcr_comm_*).  World sizes > 1 are rehearsed with a gloo stand-in in tests/test_host_cpu.py and
+tests/test_shard_files_gpu.py (RCCL refuses two ranks on one GPU)."""
 from __future__ import annotations
 
 import json
@@ -23,15 +25,42 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("workload", ["c1", "corpus"])
+@pytest.mark.parametrize("workload", ["c1", "corpus", "c1split"])
 def test_bench_one_rank_over_rccl(workload):
     env = dict(os.environ, MCR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "20",
-           "--warmup", "2", "--no-cpu-baseline", "--no-moments", "--workload", workload]
+           "--warmup", "2", "--windows", "2", "--no-cpu-baseline", "--no-moments", "--no-probe", "--workload", workload]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["validated"] is True and out["value"] > 0
     assert out["metric"] == "validated param-draws/sec"
+
+
+def test_communicator_collectives_one_rank(tmp_path, monkeypatch):
+    """mcr_comm_* directly: a world of one over RCCL (ncclAllGather / ncclAllReduce on this GPU), gather_records on top."""
+    import numpy as np
+    from mcmc_ref_hip import _ffi, shard
+    monkeypatch.setenv("MCR_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    with _ffi.Context(0) as ctx, shard.Communicator(ctx, world=1, rank=0) as comm:
+        assert (comm.world, comm.rank) == (1, 0)
+        assert list(tmp_path.iterdir()) == []                       # rank 0 removed the id file after the init
+        x = np.arange(48.0).reshape(3, 16)
+        assert np.array_equal(comm.all_gather(x), x[None])
+        assert comm.all_reduce([1.5, -2.0], "max").tolist() == [1.5, -2.0]
+        assert comm.all_reduce([3.0], "sum").tolist() == [3.0]
+        comm.barrier()
+        rec = np.random.default_rng(0).normal(size=(5, shard.RECORD_DOUBLES))
+        rec[:, shard.RECORD_FIELDS.index("model_idx")] = [2, 0, 1, 0, 2]
+        rec[:, shard.RECORD_FIELDS.index("param_idx")] = [1, 0, 0, 1, 0]
+        out = shard.gather_records(rec, comm)
+        assert np.array_equal(out, rec[[1, 3, 2, 4, 0]])
+        assert shard.gather_records(np.empty((0, shard.RECORD_DOUBLES)), comm).shape == (0, shard.RECORD_DOUBLES)
+        x3 = np.random.default_rng(1).normal(size=(6, 4, 500))
+        split = shard.summarize_param_split(ctx, x3, comm)
+        whole = ctx.summarize(x3, "pcn")
+        assert np.array_equal(split[:, shard.RECORD_FIELDS.index("ess_bulk")], whole["ess_bulk"])
+        assert split[:, shard.RECORD_FIELDS.index("param_idx")].tolist() == list(range(6))

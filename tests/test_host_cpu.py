@@ -131,11 +131,13 @@ def test_plan_shards_lpt():
 
 def _gloo_worker(rank: int, world: int, port: int, tmp: str):
     import torch.distributed as dist
-    sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
+    sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd"), str(ROOT / "tests")]
+    from gloo_comm import GlooComm
     from mcmc_ref_hip import shard
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        comm = GlooComm(dist)
         # 5 models with different parameter counts; every rank derives the same plan
         sizes = [3, 1, 4, 2, 5]
         plan = shard.plan_shards([s * 1000 for s in sizes], world)
@@ -149,8 +151,27 @@ def _gloo_worker(rank: int, world: int, port: int, tmp: str):
             summ["lag_tail"] = np.arange(P, dtype=np.int64) * 2
             recs.append(shard.pack_records(summ, m, 4, 1000))
         local = np.concatenate(recs) if recs else np.empty((0, shard.RECORD_DOUBLES))
-        allrec = shard.gather_records(local, dist)
+        allrec = shard.gather_records(local, comm)
         np.save(os.path.join(tmp, f"rank{rank}.npy"), allrec)
+        # one model split by parameter blocks: the records carry global parameter indices
+        P = 7
+        p0, p1 = shard.param_block(P, world, rank)
+        part = {k: np.arange(p0, p1, dtype=np.float64) for k in ("mean", "std", "rhat_bulk", "rhat_tail", "rhat", "ess_bulk", "ess_tail")}
+        part["q"] = np.tile(np.arange(p0, p1, dtype=np.float64)[:, None], (1, 3))
+        part["lag_bulk"] = part["lag_tail"] = np.arange(p0, p1, dtype=np.int64)
+        split = shard.gather_records(shard.pack_records(part, 0, 4, 10, param0=p0), comm)
+        np.save(os.path.join(tmp, f"split{rank}.npy"), split)
+        # a failure on ONE rank is agreed on before the data collective: every rank raises, nobody hangs
+        try:
+            shard._agree(comm, ValueError("bad file") if rank == 1 else None, "unit")
+            outcome = "no error"
+        except ValueError as e:
+            outcome = f"own: {e}"
+        except RuntimeError as e:
+            outcome = f"peer: {e}"
+        with open(os.path.join(tmp, f"agree{rank}.txt"), "w") as f:
+            f.write(outcome)
+        shard._agree(comm, None, "unit")                      # and a healthy round passes
     finally:
         dist.destroy_process_group()
 
@@ -170,6 +191,29 @@ def test_gather_records_gloo_world2(tmp_path):
     assert a[4, shard.RECORD_FIELDS.index("q50")] == 2.5 and a[4, shard.RECORD_FIELDS.index("n_draws")] == 1000
     # single-process path is the identity (sorted)
     assert np.array_equal(shard.gather_records(a[::-1]), a)
+    s0, s1 = np.load(tmp_path / "split0.npy"), np.load(tmp_path / "split1.npy")
+    assert np.array_equal(s0, s1) and list(s0[:, pi]) == list(range(7)) and list(s0[:, 0]) == list(range(7))
+    assert (tmp_path / "agree0.txt").read_text() == "peer: unit failed on rank(s) [1]; this rank (0) stops with them"
+    assert (tmp_path / "agree1.txt").read_text() == "own: bad file"
+
+
+def test_param_block_and_id_file(monkeypatch, tmp_path):
+    from mcmc_ref_hip import shard
+    for P, world in ((10000, 8), (7, 3), (2, 4), (0, 2)):
+        blocks = [shard.param_block(P, world, r) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == P
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.param_block(4, 2, 2)
+    monkeypatch.setenv("MCR_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", "29511")
+    monkeypatch.setenv("MCR_COMM_KEY", "k1")
+    a = shard._id_file(2)
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    b = shard._id_file(2)
+    assert a.parent == tmp_path and a != b and "29511" in a.name and a != shard._id_file(4)
 
 
 def test_sorting_network_is_a_sorting_network(tmp_path):

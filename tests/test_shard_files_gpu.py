@@ -68,14 +68,17 @@ def test_two_ranks_over_gloo_share_the_gpu(tmp_path):
     script.write_text(textwrap.dedent(f"""
         import os, sys
         sys.path[:0] = [{str(ROOT)!r}, {str(ROOT / 'mcmc-db_amd')!r}]
+        sys.path.insert(0, {str(ROOT / 'tests')!r})
         import numpy as np, torch.distributed as dist
+        from gloo_comm import GlooComm
         from mcmc_ref_hip import _ffi, shard
         dist.init_process_group("gloo")
-        rank, world = dist.get_rank(), dist.get_world_size()
+        comm = GlooComm(dist)
+        rank, world = comm.rank, comm.world
         paths = sorted(p for p in os.listdir({str(tmp_path)!r}) if p.endswith(".parquet"))
         paths = [os.path.join({str(tmp_path)!r}, p) for p in paths]
         with _ffi.Context(0) as ctx:
-            rec = shard.summarize_paths(ctx, paths, rank, world, dist, device="cpu")
+            rec = shard.summarize_paths(ctx, paths, comm)
             if rank == 0:
                 one = shard.summarize_paths(ctx, paths)
                 assert rec.shape == one.shape and np.array_equal(rec, one, equal_nan=True), "sharded != single"
