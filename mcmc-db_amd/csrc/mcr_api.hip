@@ -32,21 +32,21 @@ using namespace mcr;
 
 namespace {
 
-constexpr int kSortNT = 256, kSortVT = 16, kTile = kSortNT * kSortVT;
-constexpr size_t kSortLds = (size_t)(kTile + kTile / 16) * 12 + 192;
+constexpr int kTile = 4096;          // pooled draws per sorted tile / bucket capacity (256 lanes x 16 or 512 x 8)
+constexpr i64 kIdx16Max = 65535;      // pooled arrays up to this length carry 16-bit positions through the sort
 constexpr int kMaxChains = 256;
 constexpr int kMaxGridY = 65535;
 
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_ACOV_LONG, K_DIAG_LONG, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_splitters",
     "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable",
-    "k_pq_snappy", "k_pq_decode", "k_gather_rows"};
+    "k_pq_snappy", "k_pq_decode", "k_gather_rows", "k_acov_long", "k_diag_long_scan"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -56,6 +56,7 @@ struct Slot {
     bool busy = false;
     double* d_res = nullptr; double* h_res = nullptr; size_t res_cap = 0;   // doubles
     i64* d_off = nullptr; i64* h_off = nullptr; size_t off_cap = 0;          // entries
+    i64 off_C = -1, off_N = -1;     // regular chain offsets c * N already resident in d_off (no upload per call)
     mcr_summary out{};
     i64 P = 0, M = 0; int nq = 0; int C = 0;
     bool trivial_nan = false;  // M == 0: no kernels ran
@@ -94,6 +95,10 @@ struct mcr_ctx {
     void* pq_scratch = nullptr; size_t pq_scratch_bytes = 0;
     void* pq_tab = nullptr; size_t pq_tab_bytes = 0;
     void* fs_arena = nullptr; size_t fs_arena_bytes = 0;   // mcr_summarize_files: decoded draws + chain / draw ids
+    // z tables (k_ztable): a function of M alone, so they are computed once per pooled length and kept for the life of
+    // the context instead of being relaunched by every call (most recently used first; a handful of shapes is typical)
+    struct ZTab { i64 M; double* tab; };
+    std::vector<ZTab> ztabs;
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
     std::vector<int> order;  // busy slots in enqueue order
@@ -105,6 +110,7 @@ struct mcr_ctx {
     // hipGraph cache: the launch sequence of one summarize call is static for a given shape,
     // buffer set and slot, so it is captured once and replayed (removes ~5 us of host launch gap
     // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
+    int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
     bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
     std::vector<GraphEntry> graphs;
 };
@@ -209,6 +215,35 @@ int ensure_ws(mcr_ctx* ctx, size_t bytes)
     return MCR_OK;
 }
 
+// Device z table of pooled length M (2M doubles), from the context's cache; filled on first use.
+constexpr size_t kMaxZTabs = 24;
+int get_ztab(mcr_ctx* ctx, i64 M, double** out)
+{
+    for (size_t k = 0; k < ctx->ztabs.size(); ++k)
+        if (ctx->ztabs[k].M == M) {
+            const mcr_ctx::ZTab hit = ctx->ztabs[k];
+            ctx->ztabs.erase(ctx->ztabs.begin() + (long)k);
+            ctx->ztabs.insert(ctx->ztabs.begin(), hit);
+            *out = hit.tab;
+            return MCR_OK;
+        }
+    if (ctx->ztabs.size() >= kMaxZTabs) {           // the evicted table may still be read by a call in flight
+        sync_all(ctx);
+        drop_graphs(ctx);
+        hipFree(ctx->ztabs.back().tab);
+        ctx->ztabs.pop_back();
+    }
+    double* tab = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&tab, sizeof(double) * (size_t)(2 * M > 2 ? 2 * M : 2)));
+    hipLaunchKernelGGL(k_ztable, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, ctx->stream, tab, M);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // other lanes will read it: complete before anyone can
+    if (e != hipSuccess) { hipFree(tab); return fail(ctx, MCR_EHIP, "k_ztable failed: %s", hipGetErrorString(e)); }
+    ctx->ztabs.insert(ctx->ztabs.begin(), mcr_ctx::ZTab{M, tab});
+    *out = tab;
+    return MCR_OK;
+}
+
 int ensure_slot(mcr_ctx* ctx, Slot& s, size_t res_doubles, size_t off_entries)
 {
     if (res_doubles > s.res_cap || off_entries > s.off_cap) {
@@ -226,7 +261,7 @@ int ensure_slot(mcr_ctx* ctx, Slot& s, size_t res_doubles, size_t off_entries)
     if (off_entries > s.off_cap) {
         if (s.d_off) hipFree(s.d_off);
         if (s.h_off) hipHostFree(s.h_off);
-        s.d_off = nullptr; s.h_off = nullptr; s.off_cap = 0;
+        s.d_off = nullptr; s.h_off = nullptr; s.off_cap = 0; s.off_C = s.off_N = -1;
         HIP_TRY(ctx, hipMalloc((void**)&s.d_off, off_entries * sizeof(i64)));
         HIP_TRY(ctx, hipHostMalloc((void**)&s.h_off, off_entries * sizeof(i64), hipHostMallocDefault));
         s.off_cap = off_entries;
@@ -278,6 +313,7 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
                   (ranks ? (size_t)M * 32 + 1024 : 0) + (size_t)w.ntiles * 32 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) *
                       ((size_t)((nstage + kSeg - 1) / kSeg + 1) * (kSegRec + 64 * kMoreBlocks) + kChState) * 8 +
+                  (size_t)2 * (size_t)(nstage > 0 ? nstage : 1) * 8 + 2 * 4 + 2 * kPairState * 8 +
                   8 + 64;
     return w;
 }
@@ -293,13 +329,16 @@ struct PipeIn {
     // carved buffers
     double *kA, *kB, *part;
     u32 *zb, *zt;        // rank codes n2 of every draw in time order (z = ztab[n2], rank = (n2 + 1) / 2)
-    u32 *iA, *iB;
+    void *iA, *iB;       // pooled-position payload of the sort: u16 when M <= kIdx16Max, else u32
     i64* split;
     double* rec;         // [pc][2][C][nseg][kSegRec] first-pass segment records
     unsigned* more;      // [pc][2] continuation flags
     double* state;       // [pc][2][4] rho scan state
     double* chstate;     // [pc][2][C][kChState]
-    double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products 64..511
+    double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products of tier 2 (lags 64..255)
+    double* acov;        // [pc][2][n] deviation products of tier 3 (lags >= 256), listed pairs only
+    unsigned* long_count; // [1] number of pairs in the tier-3 list of this call
+    unsigned* long_list;  // [2 pc]
     i64 nstage;          // longest chain prefix the segment grid has to cover
     double* ztab;        // [2M] z of every possible tie run (shared by all parameters of the call)
     double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
@@ -330,8 +369,9 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                (const unsigned*)nullptr, a.rec);
     }
     LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, (const u32*)a.zb,
-           (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate);
-    // continuation for pairs whose first negative rho lies beyond lag 63 (others exit at once)
+           (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate,
+           a.long_count);
+    // tier 2 for pairs whose first negative rho lies beyond lag 63 (others exit at once)
     if (small) {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
@@ -343,34 +383,51 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     }
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
-           a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, (const double*)a.state,
-           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB);   // kA / kB: the sort's key buffers, free by now
+           a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
+           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB, a.long_count, a.long_list,   // kA / kB: the sort's key buffers, free by now
+           (const double*)a.part, (int)a.ntiles, a.X);
+    // tier 3 for the pairs still undecided at lag 256: rounds [256, 16384), [16384, 262144), ... over the whole chip
+    // (chains of up to 16384 draws: ONE round, i.e. two near-empty launches when no pair is listed)
+    const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
+    for (i64 L0 = kLag2; L0 < a.n;) {
+        const i64 L1 = (L0 < 16384) ? 16384 : L0 * 16;
+        const i64 lend = (L1 < a.n) ? L1 : a.n;
+        const unsigned groups = (unsigned)((lend - L0 + kLongGroup - 1) / kLongGroup);
+        LAUNCH(ctx, K_ACOV_LONG, (k_acov_long<256>), dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB,
+               a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
+               (const double*)a.state, a.acov);
+        LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
+               (const unsigned*)a.long_list, a.state, (const double*)a.acov, a.d_res, a.pc);
+        L0 = L1;
+    }
     return MCR_OK;
 }
 
 // Tile sort + (bucket partition | merge passes): leaves the pooled ascending (key, idx) order of every
 // parameter in *kin / *iin (one of the two ping-pong sets) and, on the bucket path with do_diag, z_bulk.
-int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** kout_o, u32** iout_o, bool* ranked_o)
+// (TNT, TVT): threads x draws per lane of the tile sort; (MNT, MVT): of the merge kernels (bucket merge, fold, passes).
+template <typename IdxT, int TNT, int TVT, int MNT, int MVT>
+int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
 {
+    static_assert(TNT * TVT == kTile && MNT * MVT == kTile, "tile geometry");
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
-    // 0. z lookup table of this M (tiny; the rank kernels read it instead of evaluating Phi^-1 per draw)
-    if (a.do_diag)
-        LAUNCH(ctx, K_ZTABLE, k_ztable, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, a.ztab, M);
+    constexpr size_t lds_tile = sort_lds_bytes<IdxT>(kTile);
+    // (the z lookup table of this M comes from the context's cache: get_ztab)
     // 1. tile sort (+ moment partials, + regular samples when a tile is already a run)
     const bool bucket = a.bk_B > 0;
-    LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<kSortNT, kSortVT>), dim3((unsigned)a.ntiles, py), dim3(kSortNT),
-           kSortLds, a.X, M, a.kA, a.iA, a.part, (int)a.ntiles,
+    LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<TNT, TVT, IdxT>), dim3((unsigned)a.ntiles, py), dim3(TNT),
+           lds_tile, a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles,
            (bucket && a.bk_R == kTile) ? a.samp : (double*)nullptr);
     double *kin = a.kA, *kout = a.kB;
-    u32 *iin = a.iA, *iout = a.iB;
+    IdxT *iin = (IdxT*)a.iA, *iout = (IdxT*)a.iB;
     const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
     bool ranked = false;
     // 2. pairwise merge-path passes: up to the run length of the bucket partition, or all the way
     const i64 Rstop = bucket ? a.bk_R : M;
     for (i64 R = kTile; R < Rstop; R *= 2) {
-        LAUNCH(ctx, K_MERGE, (k_merge<kSortNT, kSortVT, false>), dim3(nblk, py), dim3(kSortNT), kSortLds,
-               (const double*)kin, (const u32*)iin, kout, iout, M, R, (const double*)nullptr, pc,
+        LAUNCH(ctx, K_MERGE, (k_merge<MNT, MVT, false, IdxT>), dim3(nblk, py), dim3(MNT), lds_tile + 256,
+               (const double*)kin, (const IdxT*)iin, kout, iout, M, R, (const double*)nullptr, pc,
                (const i64*)nullptr, (u32*)nullptr);
         std::swap(kin, kout);
         std::swap(iin, iout);
@@ -388,8 +445,8 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
         LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
                M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
-        LAUNCH(ctx, K_BUCKET_MERGE, k_bucket_merge, dim3(pgrp * (unsigned)a.bk_B), dim3(256), kSortLds + 512,
-               (const double*)kin, (const u32*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
+        LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile + 512,
+               (const double*)kin, (const IdxT*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
                (const u32*)a.boff, a.do_diag ? a.zb : (u32*)nullptr, pc, a.bk_R);
         std::swap(kin, kout);
         std::swap(iin, iout);
@@ -399,6 +456,48 @@ int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, u32** iin_o, double** ko
     return MCR_OK;
 }
 
+template <typename IdxT, int NT, int VT>
+int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
+{
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + 256,
+           (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, (const double*)a.d_res, a.pc,
+           (const i64*)a.split, a.zt);
+    return MCR_OK;
+}
+
+// MCR_SORT_CFG = tile + 10 * merge.  tile: 0 = 256 lanes x 16 draws, 1 = 512 x 8.  merge: 0 = 256 x 16, 1 = 512 x 8,
+// 2 = 1024 x 4.  Measured on C1 (profiles/r02_*): the tile sort is fastest with long per-lane runs (the register
+// network does four levels for free), the merge kernels with short ones (twice the waves per CU hide the dependent
+// LDS chains of the serial merge, which has no register phase to amortise).
+template <typename IdxT>
+int sort_stage_i(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
+{
+    const int t = ctx->sort_cfg % 10, m = ctx->sort_cfg / 10;
+    if (t == 0) {
+        if (m == 0) return sort_stage_t<IdxT, 256, 16, 256, 16>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+        if (m == 1) return sort_stage_t<IdxT, 256, 16, 512, 8>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+        return sort_stage_t<IdxT, 256, 16, 1024, 4>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    }
+    if (m == 0) return sort_stage_t<IdxT, 512, 8, 256, 16>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    if (m == 1) return sort_stage_t<IdxT, 512, 8, 512, 8>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    return sort_stage_t<IdxT, 512, 8, 1024, 4>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+}
+
+int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
+{
+    return a.M <= kIdx16Max ? sort_stage_i<unsigned short>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o)
+                            : sort_stage_i<u32>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+}
+
+template <typename IdxT>
+int fold_stage_i(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
+{
+    const int m = ctx->sort_cfg / 10;
+    if (m == 0) return launch_fold<IdxT, 256, 16>(ctx, a, kin, iin, kout, iout, fgrid);
+    if (m == 1) return launch_fold<IdxT, 512, 8>(ctx, a, kin, iin, kout, iout, fgrid);
+    return launch_fold<IdxT, 1024, 4>(ctx, a, kin, iin, kout, iout, fgrid);
+}
+
 // The whole per-chunk pipeline on ctx->stream.  M >= 1, pc >= 1.
 int run_pipeline(mcr_ctx* ctx, PipeIn& a)
 {
@@ -406,7 +505,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
     const unsigned py = (unsigned)pc;
     const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
     double *kin, *kout;
-    u32 *iin, *iout;
+    void *iin, *iout;
     bool ranked;
     {
         const int rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
@@ -419,19 +518,18 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)
         if (!ranked)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
-                   (const double*)kin, (const u32*)iin, M, a.zb);
+                   (const double*)kin, (const u32*)iin, M, a.zb);       // no bucket path only beyond 512 K draws: u32 positions
         // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
-        LAUNCH(ctx, K_FOLD_MERGE, (k_merge<kSortNT, kSortVT, true>), dim3((unsigned)((pc + 7) / 8 * 8) * nblk),
-               dim3(kSortNT), kSortLds,
-               (const double*)kin, (const u32*)iin, kout, iout, M, (i64)0, (const double*)a.d_res, pc,
-               (const i64*)a.split, a.zt);
-        // 7. R-hat + ESS
-        if (a.C >= 2) {
-            const int rc = launch_diag(ctx, a);
+        const unsigned fgrid = (unsigned)((pc + 7) / 8 * 8) * nblk;
+        {
+            const int rc = M <= kIdx16Max ? fold_stage_i<unsigned short>(ctx, a, kin, iin, kout, iout, fgrid)
+                                          : fold_stage_i<u32>(ctx, a, kin, iin, kout, iout, fgrid);
             if (rc) return rc;
         }
+        // 7. R-hat + ESS (+ the finalize step, inside k_diag_combine2)
+        if (a.C >= 2) return launch_diag(ctx, a);
     }
-    // 8. finalize
+    // 8. finalize (calls without diagnostics, single chains)
     LAUNCH(ctx, K_FINALIZE, k_finalize, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0, (const double*)a.part,
            (int)a.ntiles, M, a.X, pc, (a.do_diag ? a.C : 0), a.d_res);
     return MCR_OK;
@@ -551,7 +649,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     if (!s.trivial_nan) {
         const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
         const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
-        const size_t slack = 32 * 256 + (size_t)2 * M * 8;     // + the z table (once per call, not per parameter)
+        const size_t slack = 40 * 256;
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
@@ -562,12 +660,16 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
         const int R = res_fields(nq);
         rc = ensure_slot(ctx, s, (size_t)R * (size_t)P, (size_t)C + 1);
         if (rc) return rc;
-        for (i64 c = 0; c <= C; ++c) s.h_off[c] = c * N;
+        const bool off_resident = s.off_C == C && s.off_N == N;
+        if (!off_resident) for (i64 c = 0; c <= C; ++c) s.h_off[c] = c * N;
         const bool do_diag = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
                              out->lag_bulk || out->lag_tail;
+        double* ztab = nullptr;
+        if (do_diag) { rc = get_ztab(ctx, M, &ztab); if (rc) return rc; }
         // Everything below only enqueues stream work with arguments that are a pure function of `key`.
         auto issue = [&]() -> int {
-            HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
+            if (!off_resident)
+                HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
             for (i64 p0 = 0; p0 < P; p0 += pcmax) {
                 const i64 pc = (P - p0 < pcmax) ? P - p0 : pcmax;
                 Carve cv{reinterpret_cast<char*>(ctx->ws)};
@@ -585,10 +687,13 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.rec2 = cv.take<double>((size_t)pc * 2 * cc * ns * 64 * kMoreBlocks);
                     a.chstate = cv.take<double>((size_t)pc * 2 * cc * kChState);
                     a.more = cv.take<unsigned>((size_t)pc * 2);
-                    a.state = cv.take<double>((size_t)pc * 2 * 4);
+                    a.state = cv.take<double>((size_t)pc * 2 * kPairState);
+                    a.acov = cv.take<double>((size_t)pc * 2 * (size_t)(N > 0 ? N : 1));
+                    a.long_count = cv.take<unsigned>(1);
+                    a.long_list = cv.take<unsigned>((size_t)pc * 2);
                 }
                 a.nstage = N > 0 ? N : 1;
-                a.ztab = cv.take<double>((size_t)2 * M);
+                a.ztab = ztab;
                 a.samp = cv.take<double>((size_t)pc * (wp.ntiles + 16) * 64);
                 a.cut = cv.take<u32>((size_t)pc * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
@@ -618,7 +723,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                                          (uint64_t)P, (uint64_t)sc, (uint64_t)sn, (uint64_t)sp, (uint64_t)nq,
                                          (uint64_t)si, (uint64_t)do_diag, (uint64_t)(uintptr_t)ctx->ws,
                                          (uint64_t)(uintptr_t)s.d_res, (uint64_t)(uintptr_t)s.d_off,
-                                         (uint64_t)pcmax};
+                                         (uint64_t)pcmax, (uint64_t)(uintptr_t)ztab, (uint64_t)off_resident};
             for (int k = 0; k < nq; ++k) {
                 uint64_t bits; memcpy(&bits, &q.g[k], 8);
                 key.push_back((uint64_t)q.lo[k]); key.push_back(bits);
@@ -649,6 +754,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
             if (rc) return rc;
         }
     }
+    if (!s.trivial_nan) { s.off_C = C; s.off_N = N; }
     if (!s.done) HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
     s.lane = ctx->lane;
@@ -730,8 +836,8 @@ int moments_impl(mcr_ctx* ctx, const T* src, i64 C, i64 N, i64 P, i64 sc, i64 sn
         LAUNCH(ctx, K_MOMENTS, (k_moments_cols<T>), dim3((unsigned)((P + 63) / 64), (unsigned)S), dim3(256), 0, src,
                C, N, P, sc, sn, sp, part, S);
     }
-    LAUNCH(ctx, K_MOMENTS_FINAL, (k_moments_final<T>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
-           (const double*)part, S, M, src, sp, P, d_mean, d_std, (double*)nullptr);
+    LAUNCH(ctx, K_MOMENTS_FINAL, k_moments_final, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+           (const double*)part, S, P, d_mean, d_std, (double*)nullptr);
     return MCR_OK;
 }
 
@@ -783,6 +889,10 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_WORKSPACE_MB")) { const long v = atol(env); if (v > 0) mb = (size_t)v; }
     ctx->ws_limit = mb << 20;
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
+    if (const char* env = getenv("MCR_SORT_CFG")) {
+        const int v = atoi(env);
+        if (v >= 0 && v % 10 <= 1 && v / 10 <= 2) ctx->sort_cfg = v;
+    }
     *out = ctx;
     return MCR_OK;
 }
@@ -805,6 +915,7 @@ void mcr_free(mcr_ctx* ctx)
     }
     ctx->lane_ws[0] = ctx->ws;
     for (void* w : ctx->lane_ws) if (w) hipFree(w);
+    for (const mcr_ctx::ZTab& z : ctx->ztabs) hipFree(z.tab);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->pq_stage) hipFree(ctx->pq_stage);
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
@@ -999,13 +1110,14 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         if (len >= 2 && len / 2 + nh > nstage) nstage = len / 2 + nh;
     }
     const WsPlan wp = plan_ws(M, C, true, want_dbg, nstage);
-    const size_t slack = 32 * 256 + (size_t)2 * M * 8;
+    const size_t slack = 40 * 256;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
     const int R = res_fields(0);
     rc = ensure_slot(ctx, s, (size_t)R, (size_t)C + 1);
     if (rc) return rc;
+    s.off_C = s.off_N = -1;
     memcpy(s.h_off, chain_off, sizeof(i64) * (size_t)(C + 1));
     HIP_TRY(ctx, hipMemcpyAsync(s.d_off, s.h_off, sizeof(i64) * (size_t)(C + 1), hipMemcpyHostToDevice, ctx->stream));
     Carve cv{reinterpret_cast<char*>(ctx->ws)};
@@ -1022,10 +1134,14 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.rec2 = cv.take<double>((size_t)2 * cc * ns * 64 * kMoreBlocks);
         a.chstate = cv.take<double>((size_t)2 * cc * kChState);
         a.more = cv.take<unsigned>(2);
-        a.state = cv.take<double>(8);
+        a.state = cv.take<double>(2 * kPairState);
+        a.acov = cv.take<double>((size_t)2 * (size_t)(n > 0 ? n : 1));
+        a.long_count = cv.take<unsigned>(1);
+        a.long_list = cv.take<unsigned>(2);
     }
     a.nstage = nstage;
-    a.ztab = cv.take<double>((size_t)2 * M);
+    rc = get_ztab(ctx, M, &a.ztab);
+    if (rc) return rc;
     a.samp = cv.take<double>((size_t)(wp.ntiles + 16) * 64);
     a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));
@@ -1190,7 +1306,7 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
     const size_t base = cv.off;
     HIP_TRY(ctx, hipMemcpyAsync(Xr, ref, sizeof(double) * (size_t)P * Mr, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(Xa, act, sizeof(double) * (size_t)P * Ma, hipMemcpyHostToDevice, ctx->stream));
-    double *kin, *kout; u32 *iin, *iout; bool ranked;
+    double *kin, *kout; void *iin, *iout; bool ranked;
     PipeIn a;
     {   // ascending order of the reference sample, parked in Sr
         Carve c2{reinterpret_cast<char*>(ctx->ws), base};
@@ -1329,7 +1445,11 @@ int mcr_hbm_probe(mcr_ctx* ctx, size_t bytes, int iters, double* read_gbps, doub
     if (hipMemsetAsync(a, 0x5A, bytes, st) != hipSuccess) rc = fail(ctx, MCR_EHIP, "memset failed");
     if (!rc && read_gbps) {
         const i64 nvec = (i64)(bytes / 16);
-        const double ms = best_of([&] { hipLaunchKernelGGL(k_stream_read, dim3(256 * 16), dim3(256), 0, st, (const uint4*)a, nvec, (u32*)b); });
+        double ms = 1e30;
+        for (unsigned grid : {2048u, 4096u, 8192u, 16384u, 32768u}) {
+            const double t = best_of([&] { hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, st, (const uint4*)a, nvec, (u32*)b); });
+            if (t < ms) ms = t;
+        }
         *read_gbps = (double)bytes / (ms * 1e-3) / 1e9;
     }
     if (!rc && copy_gbps) {

@@ -4,23 +4,27 @@
 // _autocorr: UNSPLIT chains, per-chain mean of the full chain, (n - lag) normaliser, stop at the
 // first negative rho), :196-201 (_variance, ddof=1).
 //
-// Structure (all fp64 VALU; LDS only as a staging buffer):
-//   k_acov_seg      grid (segment, chain, parameter x kind).  A workgroup stages 2048 draws of one
-//                   chain (+ a 72-draw halo) ONCE in LDS (swizzled so that 16-byte reads at 64-byte
-//                   lane spacing hit distinct banks) and forms the raw lag products
-//                   P_l = sum_i z_i z_{i+l} for 64 lags with an 8 (i) x 8 (lag) register tile per
-//                   lane: 12 ds_read_b128 feed 64 FMAs, so the loop runs at the fp64 FMA rate.
-//                   Products are taken on the raw z (no mean yet): the mean correction
-//                       sum (z_i - m)(z_{i+l} - m) = P_l - m (2S - head_l - tail_l) + (n - l) m^2
-//                   is applied in the combine step, which makes the pass single-sweep, independent
-//                   of chain length (any n), and fine-grained enough to fill 256 CUs.
-//                   Lag 0 gives sum z^2, so variances cost nothing extra.
-//   k_diag_combine  one wave per (parameter, kind): per-chain means / variances, split R-hat,
-//                   var_hat, and the rho terms of lags 1..63 accumulated left to right like the
-//                   reference's loop.  Pairs whose first negative rho lies beyond lag 63 are flagged.
-//   k_acov_seg      again, for flagged pairs only (others exit at once): lags 64..255.
-//   k_diag_combine2 continues the scan; beyond lag 255 (very sticky chains) it finishes with a
-//                   direct deviation-product loop over L2.
+// Structure (all fp64 VALU; LDS only as a staging buffer).  The reference walks lag by lag and stops at
+// the first negative rho; here the lags are produced in three tiers of growing width, each tier only for
+// the (parameter, kind) pairs the previous one left undecided:
+//   tier 1  k_acov_seg<FIRST>  every pair, lags 0..63.  grid (segment, chain, parameter x kind).  A workgroup
+//           stages 2048 draws of one chain (+ halo) ONCE in LDS (swizzled so that 16-byte reads at 64-byte
+//           lane spacing hit distinct banks) and forms the raw lag products P_l = sum_i z_i z_{i+l} with an
+//           8 (i) x 8 (lag) register tile per lane: 12 ds_read_b128 feed 64 FMAs, so the loop runs at the fp64
+//           FMA rate.  Products are taken on the raw z (no mean yet): the mean correction
+//               sum (z_i - m)(z_{i+l} - m) = P_l - m (2S - head_l - tail_l) + (n - l) m^2
+//           is applied in the combine step, which makes the pass single-sweep, independent of chain length
+//           (any n) and fine-grained enough to fill 256 CUs.  Lag 0 gives sum z^2, so variances cost nothing
+//           extra.  (Measured with 32 lags instead: the pass got 8 % shorter -- staging, not the FMAs, is most of
+//           it -- while three times as many C1 pairs needed tier 2; 64 stays.)
+//           k_diag_combine: one wave per pair: per-chain means / variances, split R-hat, var_hat, the rho
+//           terms of lags 1..63; pairs without a negative rho so far are flagged.
+//   tier 2  k_acov_seg<!FIRST> + k_diag_combine2: flagged pairs only (the others exit at once), lags 64..255.
+//   tier 3  k_acov_long + k_diag_long_scan, in rounds [256, 16384), [16384, 262144), ...: the pairs still undecided
+//           (sticky chains: a random walk truncates after thousands of lags) are compacted into a list, their
+//           deviations z - mean are materialised once, and EVERY CU works on them: one workgroup per
+//           (256-lag group, listed pair) accumulates the products over all chains and segments in registers.
+//           A round costs O(n x lags of the round) per listed pair and two near-empty launches otherwise.
 // A chain that is exactly constant (min == max) contributes exactly zero deviations, as in the
 // reference when its mean is exact; this keeps the W == 0 branches of _rhat / _ess exact.
 #pragma once
@@ -29,9 +33,14 @@
 namespace mcr {
 
 constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (1024 for chains of <= 1024 draws)
-constexpr int kSegRec = 80;     // doubles per first-pass record: 64 lag products + 7 scalars
-constexpr int kMoreBlocks = 3;  // continuation pass covers lags 64 .. 64 + 64*3 - 1 = 255
-enum SegField { SG_S = 64, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
+constexpr int kLag1 = 64;       // tier 1: lags 0 .. 63 (a multiple of 8, at most 64: one lag per lane in k_diag_combine)
+constexpr int kSegRec = kLag1 + 8;   // doubles per tier-1 record: the lag products + 7 scalars
+constexpr int kMoreBlocks = 3;  // tier 2: lags 64 .. 64 + 64*3 - 1 = 255
+constexpr int kLag2 = kLag1 + 64 * kMoreBlocks;   // first lag of tier 3
+constexpr int kLongGroup = 256; // lags per k_acov_long workgroup
+constexpr int kLongSlots = 2;   // listed pairs a k_acov_long launch works on at a time (its grid: lag groups x this; a launch
+                                // with nothing listed must stay cheap: every workgroup of it still has to find a CU with free LDS)
+enum SegField { SG_S = kLag1, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
 
 __device__ __forceinline__ i64 pos8(i64 j) { return j + ((j >> 3) << 1); }
 
@@ -62,22 +71,20 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
     __syncthreads();
 }
 
-// One 64-lag block of raw products for the staged segment.  A: swizzled segment (kSeg + 16),
-// B: swizzled window starting `lag base` draws later (kSeg + 80); both zero padded.  Result in
-// tot[0..63].  All NT threads must call it.
-template <int NT>
-__device__ __forceinline__ void seg_products(const double* __restrict__ A, const double* __restrict__ B,
-                                             int seglen, double* tot, double* wred)
+// One block of 8 * LG lags of raw products for a staged segment, accumulated into the lane's 8 registers.
+// A: swizzled segment (>= seglen rounded up to 8 * 64 / LG draws), B: swizzled window that starts `lag base`
+// draws later (8 * LG + 16 draws longer); both zero padded.  Lane (g, ph) = (lane % LG, lane / LG) owns lags
+// 8g .. 8g+7 of the block and draws 8 ph .. 8 ph + 7 of every span of 8 * 64 / LG draws; the waves split the spans.
+template <int NT, int LG>
+__device__ __forceinline__ void seg_accumulate(const double* __restrict__ A, const double* __restrict__ B,
+                                               int seglen, double (&acc)[8])
 {
-    constexpr int NW = NT / kWave;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane & 7, ph = lane >> 3;
-    double acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-    const int nit = (seglen + 63) >> 6;
+    constexpr int NW = NT / kWave, PH = 64 / LG, SPAN = PH * 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane % LG, ph = lane / LG;
+    const int nit = (seglen + SPAN - 1) / SPAN;
     for (int it = w; it < nit; it += NW) {
-        const int i0 = (it << 6) + (ph << 3);
+        const int i0 = it * SPAN + (ph << 3);
         const int s = i0 + (g << 3);
         const double2* pa = reinterpret_cast<const double2*>(A + 10 * (i0 >> 3));
         const double2* pb = reinterpret_cast<const double2*>(B + 10 * (s >> 3));
@@ -93,11 +100,19 @@ __device__ __forceinline__ void seg_products(const double* __restrict__ A, const
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[li] = fma(a[k], b[k + li], acc[li]);
     }
+}
+
+// Sums the lanes' registers of one lag block over phases and waves: tot[0 .. 8 * LG).  All NT threads must call it.
+template <int NT, int LG>
+__device__ __forceinline__ void seg_reduce(double (&acc)[8], double* tot, double* wred)
+{
+    constexpr int NW = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane % LG, ph = lane / LG;
 #pragma unroll
     for (int li = 0; li < 8; ++li) {
-        acc[li] += __shfl_xor(acc[li], 8, kWave);
-        acc[li] += __shfl_xor(acc[li], 16, kWave);
-        acc[li] += __shfl_xor(acc[li], 32, kWave);
+#pragma unroll
+        for (int o = LG; o < 64; o <<= 1) acc[li] += __shfl_xor(acc[li], o, kWave);
     }
     __syncthreads();  // wred / tot may still be in use
     if (ph == 0) {
@@ -105,7 +120,7 @@ __device__ __forceinline__ void seg_products(const double* __restrict__ A, const
         for (int li = 0; li < 8; ++li) wred[w * 64 + (g << 3) + li] = acc[li];
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 8 * LG) {
         double t = 0.0;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
@@ -114,8 +129,19 @@ __device__ __forceinline__ void seg_products(const double* __restrict__ A, const
     __syncthreads();
 }
 
-// FIRST == true : lags 0..63 + the segment's sums (record of kSegRec doubles), every pair.
-// FIRST == false: lags 64..64+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
+template <int NT, int LG>
+__device__ __forceinline__ void seg_products(const double* __restrict__ A, const double* __restrict__ B,
+                                             int seglen, double* tot, double* wred)
+{
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    seg_accumulate<NT, LG>(A, B, seglen, acc);
+    seg_reduce<NT, LG>(acc, tot, wred);
+}
+
+// FIRST == true : lags 0..kLag1-1 + the segment's sums (record of kSegRec doubles), every pair.
+// FIRST == false: lags kLag1..kLag1+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
 // grid (nseg, C, 2 * P); blockIdx.z = 2 * p + kind.
 template <int NT, int SEG, bool FIRST>
 __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, const u32* __restrict__ zt,
@@ -124,6 +150,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
                                                  const unsigned* __restrict__ more, double* __restrict__ rec)
 {
     constexpr int NW = NT / kWave;
+    static_assert(SEG % 128 == 0, "spans of the 32-lag tile are 128 draws");
     constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + 80) / 8 * 10;
     __shared__ __attribute__((aligned(16))) double sB[LB];
     __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
@@ -193,8 +220,8 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
             r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
             r[SG_MIN] = vmin; r[SG_MAX] = vmax;
         }
-        seg_products<NT>(sB, sB, seglen, tot, wred);
-        if (tid < 64) r[tid] = tot[tid];
+        seg_products<NT, kLag1 / 8>(sB, sB, seglen, tot, wred);
+        if (tid < kLag1) r[tid] = tot[tid];
     } else {
         if (seglen == 0) {   // nothing of [0, n) in this segment: zero record
             double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
@@ -204,11 +231,11 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
         for (int blk = 0; blk < kMoreBlocks; ++blk) {
-            const i64 lb = 64 + 64 * blk;
+            const i64 lb = kLag1 + 64 * blk;
             __syncthreads();
             for (int j = tid; j < SEG + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
             __syncthreads();
-            seg_products<NT>(sA, sB, seglen, tot, wred);
+            seg_products<NT, 8>(sA, sB, seglen, tot, wred);
             if (tid < 64) r[blk * 64 + tid] = tot[tid];
         }
     }
@@ -225,16 +252,19 @@ __device__ __forceinline__ double wave_excl_scan(double v, double& total)
     return incl - v;
 }
 
-// Per-chain state kept between the two combine kernels.
-constexpr int kChState = 6;   // mean, S, constant flag, head(64), tail(64), -
+// Per-chain state kept between the combine kernels.
+constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), -
+// Per-pair scan state: rho_sum, terms, var_hat, decided (tier 3)
+constexpr int kPairState = 4;
 
-// One wave per (parameter, kind).  grid (P, 2), block 64.
+// One wave per (parameter, kind).  grid (P, 2), block 64.  Also resets the tier-3 list of this call.
 __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                                      const double* __restrict__ ztab, i64 M,
                                                      const i64* __restrict__ off, int C, i64 n, i64 nh,
                                                      int nseg, const double* __restrict__ rec,
                                                      double* __restrict__ res, i64 P, unsigned* __restrict__ more,
-                                                     double* __restrict__ state, double* __restrict__ chstate)
+                                                     double* __restrict__ state, double* __restrict__ chstate,
+                                                     unsigned* __restrict__ long_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* cm = reinterpret_cast<double*>(smem);   // C   chain means
@@ -249,6 +279,7 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
+    if (pk == 0 && lane == 0) *long_count = 0u;     // k_diag_combine2 (a later launch on this stream) appends to the list
 
     double covsum = 0.0;   // lane l: sum over chains of sum_i (z_i - m)(z_{i+l} - m)
     for (int c = 0; c < C; ++c) {
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
         double vmin = INFINITY, vmax = -INFINITY;
         for (int sgm = 0; sgm < nseg; ++sgm) {
             const double* r = R + (i64)sgm * kSegRec;
-            Pl += r[lane]; Q += r[0];
+            Pl += (lane < kLag1) ? r[lane] : 0.0; Q += r[0];
             S += r[SG_S]; S0 += r[SG_S0]; Q0 += r[SG_Q0]; S1 += r[SG_S1]; Q1 += r[SG_Q1];
             vmin = fmin(vmin, r[SG_MIN]); vmax = fmax(vmax, r[SG_MAX]);
         }
@@ -267,8 +298,10 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
         double th, tt;
         const double head = wave_excl_scan((lane < n) ? zdec(ztab, zc[lane], M) : 0.0, th);            // sum_{i<l} z_i
         const double tail = wave_excl_scan((lane < n) ? zdec(ztab, zc[n - 1 - lane], M) : 0.0, tt);    // sum_{i>=n-l} z_i
-        if (!constant && lane < n)
+        if (!constant && lane < n && lane < kLag1)
             covsum += Pl - m * ((S - tail) + (S - head)) + (double)(n - lane) * m * m;
+        const double h32 = (kLag1 < 64) ? __shfl(head, kLag1 & 63, kWave) : th;   // sums of the first / last kLag1 draws
+        const double t32 = (kLag1 < 64) ? __shfl(tail, kLag1 & 63, kWave) : tt;
         if (lane == 0) {
             cm[c] = m;
             cq[c] = constant ? 0.0 : Q - S * m;
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
             hq[2 * c] = constant ? 0.0 : fmax(Q0 - S0 * m0, 0.0);
             hq[2 * c + 1] = constant ? 0.0 : fmax(Q1 - S1 * m1, 0.0);
             double* cs = chstate + (pk * C + c) * kChState;
-            cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = th; cs[4] = tt;
+            cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = h32; cs[4] = t32;
         }
     }
     __syncthreads();
@@ -330,11 +363,11 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
     __syncthreads();
     const double vh = bc[0];
     const int mode = (int)bc[1];
-    // ---- rho terms of lags 1..63, all lanes at once; the first negative one stops the sum
+    // ---- rho terms of lags 1..kLag1-1, one per lane; the first negative one stops the sum
     //      (diagnostics.py:171-177).  The prefix is summed with a wave tree instead of left to right.
     double rho = 0.0;
     bool neg = false;
-    const bool valid = mode == 2 && lane >= 1 && lane < n;
+    const bool valid = mode == 2 && lane >= 1 && lane < n && lane < kLag1;
     if (valid) {
         rho = (covsum / (double)(n - lane)) / ((double)C * vh);
         neg = rho < 0.0;
@@ -352,47 +385,51 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
         res[f_ess * P + p] = (double)((i64)C * n);
         res[f_lag * P + p] = 0.0;
     } else {
-        cont = (first == 64 && n > 64) ? 1u : 0u;
+        cont = (first == 64 && n > kLag1) ? 1u : 0u;
         if (!cont) {
             res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
             res[f_lag * P + p] = (double)nvalid;
         }
     }
     more[pk] = cont;
-    double* stp = state + pk * 4;
-    stp[0] = rho_sum; stp[1] = (double)nvalid; stp[2] = vh;
+    double* stp = state + pk * kPairState;
+    stp[0] = rho_sum; stp[1] = (double)nvalid; stp[2] = vh; stp[3] = 1.0;      // [3]: decided, as far as tier 3 is concerned
 }
 
-// Continuation for flagged pairs: lags 64..255 from the second k_acov_seg pass, then (very sticky
-// chains only) a direct deviation-product loop over L2 from lag 256.  grid (P, 2), block 256.
+// Tier 2 for flagged pairs: lags kLag1..kLag2-1 from the second k_acov_seg pass.  A pair that is still undecided
+// (very sticky chains) gets its deviations z - mean materialised once ([M] doubles per pair: the sort's key
+// buffers, free by now) and a slot in the tier-3 list.  grid (P, 2), block 1024.
 __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                                        const double* __restrict__ ztab, i64 M,
                                                        const i64* __restrict__ off, int C, i64 n, int nseg,
                                                        const double* __restrict__ rec2,
                                                        const unsigned* __restrict__ more,
-                                                       const double* __restrict__ state,
+                                                       double* __restrict__ state,
                                                        const double* __restrict__ chstate,
                                                        double* __restrict__ res, i64 P,
-                                                       double* __restrict__ dev_b, double* __restrict__ dev_t)
+                                                       double* __restrict__ dev_b, double* __restrict__ dev_t,
+                                                       unsigned* __restrict__ long_count, unsigned* __restrict__ long_list,
+                                                       const double* __restrict__ part, int ntiles,
+                                                       const double* __restrict__ X)
 {
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
+    // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
+    // k_finalize, done here by the first thread of the parameter's first workgroup
+    if (kind == 0 && threadIdx.x == 0) finalize_param(part, ntiles, M, X, P, C, res, p);
     if (more[pk] == 0u) return;
-    __shared__ double tot[64];
-    __shared__ double wred[16 * 64];
-    __shared__ double ctl[2];
-    const int nwv = (int)(blockDim.x >> 6);             // 16 waves: the direct loop below is latency-bound
+    __shared__ double ctl[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u32* z = (kind ? zt : zb) + p * M;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-    double rho_sum = state[pk * 4 + 0];
-    i64 terms = (i64)state[pk * 4 + 1];
-    const double vhat = state[pk * 4 + 2];
+    double rho_sum = state[pk * kPairState + 0];
+    i64 terms = (i64)state[pk * kPairState + 1];
+    const double vhat = state[pk * kPairState + 2];
     bool stop = false;
 
-    // ---- lags 64..255: wave 0 combines the records block by block ----
+    // ---- lags kLag1..kLag2-1: wave 0 combines the records block by block ----
     // hb[c] / tb[c]: running sums of the first / last `lb` draws of chain c (head / tail bases)
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     double* hb = reinterpret_cast<double*>(smem2);
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     for (int c = tid; c < C; c += (int)blockDim.x) { hb[c] = chstate[(pk * C + c) * kChState + 3]; tb[c] = chstate[(pk * C + c) * kChState + 4]; }
     __syncthreads();
     for (int blk = 0; blk < kMoreBlocks && !stop; ++blk) {
-        const i64 lb = 64 + 64 * blk;
+        const i64 lb = kLag1 + 64 * blk;
         if (lb >= n) break;
         if (w == 0) {
             double covsum = 0.0;
@@ -427,68 +464,139 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
             const int first = negmask ? (__ffsll((long long)negmask) - 1) : 64;
             const double add = wave_sum((valid && lane < first) ? rho : 0.0);
             const int cnt = (int)__popcll(__ballot(valid && lane < first));
-            if (lane == 0) { ctl[0] = (first < 64) ? 1.0 : 0.0; ctl[1] = add; tot[0] = (double)cnt; }
+            if (lane == 0) { ctl[0] = (first < 64) ? 1.0 : 0.0; ctl[1] = add; ctl[2] = (double)cnt; }
         }
         __syncthreads();
         rho_sum += ctl[1];
-        terms += (i64)tot[0];
+        terms += (i64)ctl[2];
         stop = ctl[0] != 0.0;
         __syncthreads();
     }
-    // ---- beyond lag 255: direct products of deviations, 64 lags per round (lane = lag), the waves split i.
-    //      The deviations z - mean are materialised once in scratch ([M] doubles per pair: the sort's key buffers,
-    //      free by now), so the loop reads coalesced doubles instead of gathering the z table per product. ----
-    double* dev = (kind ? dev_t : dev_b) + p * M;
-    if (64 + 64 * kMoreBlocks < n && !stop) {
-        for (int c = 0; c < C; ++c) {
-            const double* cs = chstate + (pk * C + c) * kChState;
-            const bool konst = cs[2] != 0.0;
-            const double m = cs[0];
-            const u32* zc = z + off[c];
-            double* dc = dev + off[c];
-            for (i64 i = tid; i < n; i += blockDim.x) dc[i] = konst ? 0.0 : zdec(ztab, zc[i], M) - m;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (i64 lb = 64 + 64 * kMoreBlocks; lb < n && !stop; lb += 64) {
-        const i64 lag = lb + lane;
-        double acc = 0.0, acc2 = 0.0;
-        for (int c = 0; c < C; ++c) {
-            const double* dc = dev + off[c];
-            i64 i = (i64)w * 8;
-            for (; i + 7 + lag < n; i += 8 * nwv) {
-                double a[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { a[u] = dc[i + u]; b[u] = dc[i + u + lag]; }
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) { acc = fma(a[u], b[u], acc); acc2 = fma(a[u + 1], b[u + 1], acc2); }
-            }
-            for (int u = 0; u < 8; ++u)
-                if (i + u + lag < n) acc = fma(dc[i + u], dc[i + u + lag], acc);
-        }
-        acc += acc2;
-        __syncthreads();
-        wred[w * 64 + lane] = acc;
-        __syncthreads();
-        if (tid < 64) { double t = 0.0; for (int ww = 0; ww < nwv; ++ww) t += wred[ww * 64 + tid]; tot[tid] = t; }
-        __syncthreads();
+    if (stop || kLag2 >= n) {
         if (tid == 0) {
-            double st = 0.0;
-            for (i64 l = 0; l < 64 && lb + l < n; ++l) {
-                const double rho = (tot[l] / (double)(n - (lb + l))) / ((double)C * vhat);
-                if (rho < 0.0) { st = 1.0; break; }
-                rho_sum += rho;
-                ++terms;
-            }
-            ctl[0] = st;
+            res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+            res[f_lag * P + p] = (double)terms;
         }
-        __syncthreads();
-        stop = ctl[0] != 0.0;
+        return;
+    }
+    // ---- still undecided at lag kLag2: hand the pair to tier 3 ----
+    double* dev = (kind ? dev_t : dev_b) + p * M;
+    for (int c = 0; c < C; ++c) {
+        const double* cs = chstate + (pk * C + c) * kChState;
+        const bool konst = cs[2] != 0.0;
+        const double m = cs[0];
+        const u32* zc = z + off[c];
+        double* dc = dev + off[c];
+        for (i64 i = tid; i < n; i += blockDim.x) dc[i] = konst ? 0.0 : zdec(ztab, zc[i], M) - m;
     }
     if (tid == 0) {
-        res[f_ess * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
-        res[f_lag * P + p] = (double)terms;
+        double* stp = state + pk * kPairState;
+        stp[0] = rho_sum; stp[1] = (double)terms; stp[3] = 0.0;
+        long_list[atomicAdd(long_count, 1u)] = (unsigned)pk;     // order of the list is irrelevant: pairs are independent
+    }
+}
+
+// Tier 3 products.  grid (lag groups of the round, kLongSlots), block NT.  Workgroup (g, s) takes the listed pairs
+// s, s + kLongSlots, ... and for each accumulates, over ALL chains and segments, the deviation products of lags
+// [L0 + 256 g, L0 + 256 g + 256) in registers (4 blocks of 64 lags: one staging of the segment serves 256 lags),
+// then writes acov[pair][lag] = sum_c sum_i d_c[i] d_c[i + lag] once.  Deterministic: fixed summation order.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev_b, const double* __restrict__ dev_t,
+                                                  i64 M, const i64* __restrict__ off, int C, i64 n, i64 L0, i64 L1,
+                                                  const unsigned* __restrict__ long_count,
+                                                  const unsigned* __restrict__ long_list,
+                                                  const double* __restrict__ state, double* __restrict__ acov)
+{
+    constexpr int NW = NT / kWave, SEG = kSeg;
+    constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + kLongGroup + 16) / 8 * 10;
+    __shared__ __attribute__((aligned(16))) double sA[LA];
+    __shared__ __attribute__((aligned(16))) double sB[LB];
+    __shared__ double tot[64];
+    __shared__ double wred[NW * 64];
+    const int tid = threadIdx.x;
+    const unsigned count = *long_count;
+    const i64 lend = (L1 < n) ? L1 : n;
+    const i64 lbase = L0 + (i64)kLongGroup * blockIdx.x;
+    if (lbase >= lend) return;
+    for (unsigned slot = blockIdx.y; slot < count; slot += gridDim.y) {
+        const i64 pk = long_list[slot];
+        if (state[pk * kPairState + 3] != 0.0) continue;            // decided in an earlier round
+        const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
+        double acc[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[b][i] = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double* dc = dev + off[c];
+            for (i64 s0 = 0; s0 + lbase < n; s0 += SEG) {           // beyond that every product has a factor past the chain
+                const int seglen = (int)((n - s0 < (i64)SEG) ? n - s0 : (i64)SEG);
+                __syncthreads();
+                for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? dc[g] : 0.0; }
+                for (int j = tid; j < SEG + kLongGroup + 16; j += NT) { const i64 g = s0 + lbase + j; sB[pos8(j)] = (g < n) ? dc[g] : 0.0; }
+                __syncthreads();
+#pragma unroll
+                for (int b = 0; b < 4; ++b) seg_accumulate<NT, 8>(sA, sB + 80 * b, seglen, acc[b]);     // 64 draws = 80 swizzled slots
+            }
+        }
+        double* out = acov + pk * n;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            seg_reduce<NT, 8>(acc[b], tot, wred);
+            const i64 lag = lbase + 64 * b + tid;
+            if (tid < 64 && lag < lend) out[lag] = tot[tid];
+            __syncthreads();
+        }
+    }
+}
+
+// Tier 3 scan of one round's lags [L0, min(L1, n)) for the listed pairs: first negative rho, ordered prefix sum.
+// grid (kLongSlots), block 256.
+__global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i64 L1,
+                                                        const unsigned* __restrict__ long_count,
+                                                        const unsigned* __restrict__ long_list,
+                                                        double* __restrict__ state, const double* __restrict__ acov,
+                                                        double* __restrict__ res, i64 P)
+{
+    __shared__ double red[4];
+    __shared__ long long sfirst;
+    const int tid = threadIdx.x;
+    const unsigned count = *long_count;
+    const i64 lend = (L1 < n) ? L1 : n;
+    for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        const i64 pk = long_list[slot];
+        double* stp = state + pk * kPairState;
+        if (stp[3] != 0.0) continue;
+        const double vhat = stp[2];
+        const double* a = acov + pk * n;
+        const double den = (double)C * vhat;
+        if (tid == 0) sfirst = (long long)lend;
+        __syncthreads();
+        long long mine = (long long)lend;
+        for (i64 l = L0 + tid; l < lend; l += 256) {
+            const double rho = (a[l] / (double)(n - l)) / den;
+            if (rho < 0.0) { mine = l; break; }                    // the thread's lags ascend: its first negative
+        }
+        if (mine < (long long)lend) atomicMin(&sfirst, mine);
+        __syncthreads();
+        const i64 first = (i64)sfirst;
+        double s = 0.0;
+        for (i64 l = L0 + tid; l < first; l += 256) s += (a[l] / (double)(n - l)) / den;
+        s = block_sum<256>(s, red);
+        if (tid == 0) {
+            const double rho_sum = stp[0] + s;
+            const double terms = stp[1] + (double)(first - L0);
+            if (first < lend || lend >= n) {
+                const i64 p = pk >> 1;
+                const int kind = (int)(pk & 1);
+                res[(kind ? R_ESS_TAIL : R_ESS_BULK) * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+                res[(kind ? R_LAG_TAIL : R_LAG_BULK) * P + p] = terms;
+                stp[3] = 1.0;
+            } else {
+                stp[0] = rho_sum; stp[1] = terms;
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -118,13 +118,38 @@ __global__ __launch_bounds__(256) void k_ingest_transpose(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Streaming moments (a2/a3/a4): one HBM pass, shifted sums S1 = sum(x-K), S2 = sum((x-K)^2) with
-// K = the parameter's first draw, so mean = K + S1/M, var = (S2 - S1^2/M)/M without catastrophic
-// cancellation.  Mirrors np.mean / np.std(ddof=0) (src/mcmc_ref/backends_numpy.py:41-42),
-// pc.mean / pc.stddev (backends_arrow.py:38-39) and compute_basic_stats (compare.py:58-64).
-// part[(p*S + s)*4 + {0,1,2}] = S1, S2, non-finite count.
+// Streaming moments (a2/a3/a4): one HBM pass.  Every workgroup accumulates shifted sums S1 = sum(x-K),
+// S2 = sum((x-K)^2) of ITS slice around a pivot K taken from that slice (the mean of its first 64 draws, so a single
+// outlying draw cannot become the pivot), converts them to the slice's (count, mean, M2 = sum (x - mean)^2), and the
+// finisher merges the slices with Chan's pairwise update.  Same result as the reference's two-pass forms -- np.mean /
+// np.std(ddof=0) (src/mcmc_ref/backends_numpy.py:41-42), pc.mean / pc.stddev (backends_arrow.py:38-39),
+// compute_basic_stats (compare.py:58-64) -- to a few ulp even when a chain starts far from its bulk (an unconverged
+// `actual` handed to compare()): the cancellation is bounded by the spread INSIDE a slice, not by |first draw - mean|.
+// part[(p*S + s)*4 + {0,1,2,3}] = slice mean, slice M2, non-finite count, slice length.
 // rows variant: grid (S, P); the block streams a contiguous slice of X[p][.] with 16-byte loads.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_slice_moments(double* o, double K, double s1, double s2, double bad, double n)
+{
+    const double dm = (n > 0.0) ? s1 / n : 0.0;
+    double m2 = s2 - s1 * dm;
+    if (!(m2 >= 0.0) && !isnan(m2)) m2 = 0.0;          // tiny negative from rounding; NaN / +inf pass through
+    o[0] = K + dm; o[1] = m2; o[2] = bad; o[3] = n;
+}
+
+// (mean, M2, bad) of a parameter from its S slice records (fixed order): Chan et al.'s combination
+//     M2 = sum_s M2_s + sum_s n_s (mean_s - mean)^2,  mean = m_0 + sum_s n_s (mean_s - m_0) / N.
+__device__ __forceinline__ void merge_slice_moments(const double* __restrict__ rec, int S, double& mean, double& m2,
+                                                    double& bad, double& n)
+{
+    const double m0 = rec[0];
+    double acc = 0.0, N = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) { const double* o = rec + (i64)s * 4; acc += o[3] * (o[0] - m0); N += o[3]; b += o[2]; }
+    const double mu = (N > 0.0) ? m0 + acc / N : NAN;
+    double q = 0.0;
+    for (int s = 0; s < S; ++s) { const double* o = rec + (i64)s * 4; const double d = o[0] - mu; q += o[1]; q = fma(o[3] * d, d, q); }
+    mean = mu; m2 = q; bad = b; n = N;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i64 M, i64 pstride,
                                                       double* __restrict__ part, int S)
@@ -133,11 +158,19 @@ __global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i
     const i64 p = blockIdx.y;
     const int s = blockIdx.x;
     const T* x = X + p * pstride;
-    const double K = (double)x[0];
     constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
     i64 per = (M + S - 1) / S;
     per = (per + V - 1) / V * V;
     const i64 b = s * per, e = (b + per < M) ? b + per : M;
+    // pivot: mean of the slice's first (up to) 64 draws, the same value in every lane
+    double K = 0.0;
+    {
+        const int lane = threadIdx.x & 63;
+        const i64 cnt = (e - b < 64) ? e - b : 64;
+        K = (lane < cnt) ? (double)x[b + lane] : 0.0;
+        K = wave_sum(K) / (double)(cnt > 0 ? cnt : 1);
+        if (!isfinite(K)) K = 0.0;                      // non-finite draws: the call is rejected anyway; keep the sums defined
+    }
     double s1 = 0.0, s2 = 0.0, bad = 0.0;
     auto acc1 = [&](double v) {
         const double d = v - K;
@@ -172,10 +205,7 @@ __global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i
     s1 = block_sum<256>(s1, red);
     s2 = block_sum<256>(s2, red);
     bad = block_sum<256>(bad, red);
-    if (threadIdx.x == 0) {
-        double* o = part + (p * S + s) * 4;
-        o[0] = s1; o[1] = s2; o[2] = bad; o[3] = 0.0;
-    }
+    if (threadIdx.x == 0) store_slice_moments(part + (p * S + s) * 4, K, s1, s2, bad, (double)(e > b ? e - b : 0));
 }
 
 // strided variant ([C][N][P]-like tensors, stride_p == 1): lanes run along p, each thread owns one
@@ -191,9 +221,10 @@ __global__ __launch_bounds__(256) void k_moments_cols(const T* __restrict__ src,
     const int s = blockIdx.y;
     const i64 M = C * N;
     const i64 per = (M + S - 1) / S, b = s * per, e = (b + per < M) ? b + per : M;
-    double s1 = 0.0, s2 = 0.0, bad = 0.0;
-    if (p < P) {
-        const double K = (double)src[p * sp];
+    double s1 = 0.0, s2 = 0.0, bad = 0.0, K = 0.0;
+    if (p < P && b < e) {
+        { const i64 c = b / N, t = b - c * N; K = (double)src[c * sc + t * sn + p * sp]; }     // pivot: first draw of the slice
+        if (!isfinite(K)) K = 0.0;
         for (i64 r = b + ty; r < e; r += 4) {
             const i64 c = r / N, t = r - c * N;
             const double v = (double)src[c * sc + t * sn + p * sp], d = v - K;
@@ -203,36 +234,25 @@ __global__ __launch_bounds__(256) void k_moments_cols(const T* __restrict__ src,
     }
     sh[0][ty][tx] = s1; sh[1][ty][tx] = s2; sh[2][ty][tx] = bad;
     __syncthreads();
-    if (ty == 0 && p < P) {
-        double* o = part + (p * S + s) * 4;
-        o[0] = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
-        o[1] = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
-        o[2] = sh[2][0][tx] + sh[2][1][tx] + sh[2][2][tx] + sh[2][3][tx];
-        o[3] = 0.0;
-    }
+    if (ty == 0 && p < P)
+        store_slice_moments(part + (p * S + s) * 4, K, sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx],
+                            sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx],
+                            sh[2][0][tx] + sh[2][1][tx] + sh[2][2][tx] + sh[2][3][tx], (double)(e > b ? e - b : 0));
 }
 
-// mean/std from S partials per parameter (fixed summation order).  first[p] = the shift K.
-// When res == nullptr writes mean[p], std[p] directly (mcr_moments_dev / mcr_basic_stats).
-template <typename T>
-__global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, const T* __restrict__ src,
-                                i64 kstride, i64 P, double* __restrict__ mean, double* __restrict__ stdv,
-                                double* __restrict__ bad)
+// mean/std from the S slice records of every parameter (fixed summation order).
+// Writes mean[p], std[p] directly (mcr_moments_dev / mcr_basic_stats).
+__global__ void k_moments_final(const double* __restrict__ part, int S, i64 P, double* __restrict__ mean,
+                                double* __restrict__ stdv, double* __restrict__ bad)
 {
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    double s1 = 0.0, s2 = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const double* o = part + (p * S + s) * 4;
-        s1 += o[0]; s2 += o[1]; b += o[2];
-    }
-    const double K = (double)src[p * kstride];
-    const double m = (double)M;
-    const double mu = s1 / m;
-    double var = (s2 - s1 * mu) / m;
-    if (isinf(s2)) var = INFINITY;          // squares overflowed: inf like np.std, not inf - inf
+    double mu, m2, b, n;
+    merge_slice_moments(part + p * S * 4, S, mu, m2, b, n);
+    double var = m2 / n;
+    if (isinf(m2)) var = INFINITY;          // squares overflowed: inf like np.std
     else if (!(var >= 0.0)) var = 0.0;
-    mean[p] = K + mu;
+    mean[p] = mu;
     stdv[p] = sqrt(var);
     if (bad) bad[p] = b;
 }
@@ -242,7 +262,7 @@ __global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, c
 // (thread-local odd-even network over VT registers, then log2(NT) merge-path levels), carrying the
 // pooled position as a u32 payload.  Spec: the `sorted(flat, key=...)` of
 // src/mcmc_ref/diagnostics.py:110 (stability is irrelevant: ties share one average rank).
-// Also emits the shifted moment partials of its tile (so the draws are read from HBM once).
+// Also emits the moments (count, mean, M2) of its tile (so the draws are read from HBM once).
 // Partial tiles are padded with +inf (draws are finite or the call fails with MCR_ENONFINITE).
 // ------------------------------------------------------------------------------------------------
 // 16 registers per lane, fully static 60-comparator network (mcr_sortnet.h): every index is a
@@ -251,7 +271,7 @@ __global__ void k_moments_final(const double* __restrict__ part, int S, i64 M, c
 template <int VT>
 __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 {
-    static_assert(VT == 16, "the sorting network is for 16 items per lane");
+    static_assert(VT == 16 || VT == 8, "sorting networks exist for 16 and 8 items per lane");
 #define MCR_CE(a, b)                                                        \
     {                                                                       \
         const bool sw = k[b] < k[a];                                        \
@@ -259,16 +279,16 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
         const u32 ilo = sw ? ix[b] : ix[a], ihi = sw ? ix[a] : ix[b];       \
         k[a] = lo; k[b] = hi; ix[a] = ilo; ix[b] = ihi;                     \
     }
-    MCR_NET16(MCR_CE)
+    if constexpr (VT == 16) { MCR_NET16(MCR_CE) } else { MCR_NET8(MCR_CE) }
 #undef MCR_CE
 }
 
-// Serial merge of up to VT outputs from LDS runs A = skey[pos(a0 + .)] (na items) and
-// B = skey[pos(b0 + .)] (nb items), starting at (ai, bi).  src[i] = LDS slot the output came from.
-// Branch-free: an exhausted run shows a +inf head, the LDS read of the next head is unconditional
-// (one slot past a run is still inside the workgroup's LDS) and masked afterwards.  Keys of real
-// draws are finite, so they are never confused with the sentinel; among +inf pads the payload may
-// come from either side, which is irrelevant (pads are never written out).  ~20 VALU per output.
+// Serial merge of up to VT outputs from LDS runs A = skey[pos16(a0 + .)] (na items) and
+// B = skey[pos16(b0 + .)] (nb items), starting at (ai, bi).  src[i] = LDS slot the output came from.
+// Branch-free.  Which run is exhausted is decided on the POINTERS (two integer compares whose lane masks are combined
+// with the key compare on the scalar unit), so the head values need no sanitising: the LDS read of the next head is
+// unconditional (one slot past a run is still inside the workgroup's LDS) and whatever it returns past the end of a
+// run is never selected.  Ties take from A.  ~19 VALU per output (25 with the +inf substitution this replaced).
 template <int VT>
 __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na, int b0, int nb, int ai,
                                              int bi, int nout, double (&k)[VT], int (&src)[VT])
@@ -276,20 +296,16 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
     int pa = a0 + ai, pb = b0 + bi;
     const int ea = a0 + na, eb = b0 + nb;
     double ak = skey[pos16(pa)], bk = skey[pos16(pb)];
-    ak = (pa < ea) ? ak : INFINITY;
-    bk = (pb < eb) ? bk : INFINITY;
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         if (i < nout) {
-            const bool takeA = !(bk < ak);
+            const bool takeA = (pb >= eb) | ((pa < ea) & !(bk < ak));
             k[i] = takeA ? ak : bk;
             src[i] = takeA ? pa : pb;
             pa += takeA ? 1 : 0;
             pb += takeA ? 0 : 1;
             const int pn = takeA ? pa : pb;
-            const int en = takeA ? ea : eb;
-            double nv = skey[pos16(pn)];
-            nv = (pn < en) ? nv : INFINITY;
+            const double nv = skey[pos16(pn)];
             ak = takeA ? nv : ak;
             bk = takeA ? bk : nv;
         } else {
@@ -298,35 +314,37 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
     }
 }
 
-template <int NT, int VT>
+// IdxT = the pooled-position payload: u16 when M < 65536 (C1 and every packaged model: 10 bytes per LDS slot, so FOUR
+// 4096-draw tiles are resident per CU instead of three, and 10 instead of 12 bytes per draw go to HBM and back),
+// u32 otherwise.  LDS: skey[T] then sidx[T], nothing else -- the single read "one slot past the last run" of
+// serial_merge lands on sidx[0] (in bounds, value never selected); the reduction scratch reuses skey at the end.
+template <typename IdxT> constexpr size_t sort_lds_bytes(int T) { return (size_t)T * (8 + sizeof(IdxT)); }
+
+template <int NT, int VT, typename IdxT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, i64 M,
-                                                  double* __restrict__ keys, u32* __restrict__ idx,
+                                                  double* __restrict__ keys, IdxT* __restrict__ idx,
                                                   double* __restrict__ part, int ntiles,
                                                   double* __restrict__ samp)
 {
     constexpr int T = NT * VT;
-    constexpr int TP = T + T / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* skey = reinterpret_cast<double*>(smem);
-    u32* sidx = reinterpret_cast<u32*>(skey + TP);
-    double* red = reinterpret_cast<double*>(sidx + TP);  // TP*12 is a multiple of 8
+    IdxT* sidx = reinterpret_cast<IdxT*>(skey + T);
+    double* red = skey;      // only after the sorted tile has left LDS (barrier below)
 
     const int tid = threadIdx.x, tile = blockIdx.x;
     const i64 p = blockIdx.y;
     const i64 base = (i64)tile * T;
     const int count = (int)((M - base < (i64)T) ? M - base : (i64)T);
     const double* src = X + p * M + base;
-    const double K = X[p * M];
 
-    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    double bad = 0.0;
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         const int e = i * NT + tid;
         double v = INFINITY;
         if (e < count) {
             v = src[e];
-            const double d = v - K;
-            s1 += d; s2 = fma(d, d, s2);
             bad += isfinite(v) ? 0.0 : 1.0;
         }
         skey[pos16(e)] = v;
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
     for (int i = 0; i < VT; ++i) {
         const int e = tid * VT + i;
         skey[pos16(e)] = k[i];
-        sidx[pos16(e)] = ix[i];
+        sidx[pos16(e)] = (IdxT)ix[i];
     }
     __syncthreads();
 
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
         for (int i = 0; i < VT; ++i) {
             const int e = tid * VT + i;
             skey[pos16(e)] = k[i];
-            sidx[pos16(e)] = ix[i];
+            sidx[pos16(e)] = (IdxT)ix[i];
         }
         __syncthreads();
     }
@@ -382,12 +400,23 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
         const int e = 64 * tid + 63;
         samp[(p * ntiles + tile) * (T / 64) + tid] = (e < count) ? skey[pos16(e)] : INFINITY;
     }
+    __syncthreads();                 // `red` aliases skey from here on
+    // Moments of the tile, two-pass like the reference (mean first, then squared deviations; compare.py:62-63), from the
+    // lane's VT sorted draws still in registers (the draws are read from HBM exactly once): k_finalize merges the
+    // tiles with Chan's update.  Slots at or beyond `count` hold the +inf pads.
+    double s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) s1 += (tid * VT + i < count) ? k[i] : 0.0;
     s1 = block_sum<NT>(s1, red);
+    const double mt = s1 / (double)count;
+    double s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < VT; ++i) { const double d = (tid * VT + i < count) ? k[i] - mt : 0.0; s2 = fma(d, d, s2); }
     s2 = block_sum<NT>(s2, red);
     bad = block_sum<NT>(bad, red);
     if (tid == 0) {
         double* o = part + (p * ntiles + tile) * 4;
-        o[0] = s1; o[1] = s2; o[2] = bad; o[3] = 0.0;
+        o[0] = mt; o[1] = s2; o[2] = bad; o[3] = (double)count;
     }
 }
 
@@ -452,18 +481,17 @@ __device__ __forceinline__ void block_tie_runs(const double* skey, int total, in
 // rounding is monotone), against the values at or above it (x - med).  This replaces the second
 // full sort of src/mcmc_ref/diagnostics.py:93-98 + :110.  Each workgroup owns OB = NT*VT outputs.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int VT, bool FOLD>
-__global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
-                                              double* __restrict__ kout, u32* __restrict__ iout, i64 M,
+template <int NT, int VT, bool FOLD, typename IdxT>
+__global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const IdxT* __restrict__ iin,
+                                              double* __restrict__ kout, IdxT* __restrict__ iout, i64 M,
                                               i64 R, const double* __restrict__ res, i64 P,
                                               const i64* __restrict__ split, u32* __restrict__ z)
 {
     constexpr int OB = NT * VT;
-    constexpr int TP = OB + OB / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* skey = reinterpret_cast<double*>(smem);
-    u32* sidx = reinterpret_cast<u32*>(skey + TP);
-    i64* sh = reinterpret_cast<i64*>(sidx + TP);
+    IdxT* sidx = reinterpret_cast<IdxT*>(skey + OB);
+    i64* sh = reinterpret_cast<i64*>(sidx + OB);            // 8-byte aligned: OB * sizeof(IdxT) is a multiple of 8
 
     const int tid = threadIdx.x;
     i64 p = blockIdx.y;
@@ -474,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     const i64 o0 = (i64)blk * OB;
     if (o0 >= M) return;
     const double* kp = kin + p * M;
-    const u32* ip = iin + p * M;
+    const IdxT* ip = iin + p * M;
 
     i64 abase, na, bbase, nb, d0;
     double med = 0.0;
@@ -519,7 +547,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
             id = ip[g];
         }
         skey[pos16(e)] = v;
-        sidx[pos16(e)] = id;
+        sidx[pos16(e)] = (IdxT)id;
     }
     __syncthreads();
 
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     for (int i = 0; i < VT; ++i) {
         if (i < nout) {
             skey[pos16(diag + i)] = k[i];
-            sidx[pos16(diag + i)] = ix[i];
+            sidx[pos16(diag + i)] = (IdxT)ix[i];
         }
     }
     __syncthreads();
@@ -594,7 +622,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
             i64 gs = d0 + rs[i], ge = d0 + re[i];
             if (ext0 && v == vfirst) gs = gfirst;
             if (ext1 && v == vlast) ge = glast;
-            const u32 t_idx = min(sidx[pos16(e)], (u32)(M - 1));     // stale order after a rejected (NaN) partition
+            const u32 t_idx = min((u32)sidx[pos16(e)], (u32)(M - 1));     // stale order after a rejected (NaN) partition
             z[p * M + t_idx] = (u32)(gs + ge);            // code of the tie run: rank = (code + 1) / 2
         }
     }
@@ -730,17 +758,19 @@ __global__ __launch_bounds__(256) void k_sample_runs(const double* __restrict__ 
 // edge are completed with lower/upper bounds over the k sorted tiles, which are complete in memory.
 // Replaces log2(k) global merge passes + k_rank_z of the first version.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__ kin, const u32* __restrict__ iin,
-                                                      double* __restrict__ kout, u32* __restrict__ iout, i64 M,
+template <int NT, int VT, typename IdxT>
+__global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ kin, const IdxT* __restrict__ iin,
+                                                      double* __restrict__ kout, IdxT* __restrict__ iout, i64 M,
                                                       int k, int B, const u32* __restrict__ cut,
                                                       const u32* __restrict__ boff, u32* __restrict__ z, i64 P,
                                                       i64 R)
 {
-    constexpr int NT = 256, VT = 16, T = 4096, TP = T + T / 16;
+    constexpr int T = NT * VT;
+    static_assert(T == 4096, "the partition bound of k_splitters assumes 4096-slot buckets");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* skey = reinterpret_cast<double*>(smem);
-    u32* sidx = reinterpret_cast<u32*>(skey + TP);
-    int* sst = reinterpret_cast<int*>(sidx + TP);   // padded piece starts [k+1], then scratch
+    IdxT* sidx = reinterpret_cast<IdxT*>(skey + T);
+    int* sst = reinterpret_cast<int*>(sidx + T);    // padded piece starts [k+1], then scratch
     int* spl = sst + 40;                            // piece lengths [k]
     int* sps = spl + 40;                            // piece source offsets in tile [k]
     i64* sedge = reinterpret_cast<i64*>(sps + 40);  // [4] global run bounds of the edge values
@@ -750,7 +780,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     int b;
     if (!xcd_map(P, B, p, b)) return;
     const double* kp = kin + p * M;
-    const u32* ip = iin + p * M;
+    const IdxT* ip = iin + p * M;
     const u32* c0 = cut + (p * (B + 1) + b) * k;
     const u32* c1 = c0 + k;
     if (tid == 0) {
@@ -774,7 +804,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
         for (int step = 8; step > 0; step >>= 1)
             if (t + step < k && e >= sst[t + step]) t += step;
         const int o = e - sst[t];
-        double v = INFINITY; u32 id = 0xFFFFFFFFu;
+        double v = INFINITY; IdxT id = (IdxT)~(IdxT)0;
         if (o < spl[t]) { const i64 g = (i64)t * R + sps[t] + o; v = kp[g]; id = ip[g]; }
         skey[pos16(e)] = v; sidx[pos16(e)] = id;
     }
@@ -784,6 +814,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
     for (int w = 1; w < k; w <<= 1) {
         double kk[VT]; int srcs[VT]; u32 ix[VT];
         const bool active = chunk0 < padded;
+        bool moved = false;
         if (active) {
             int ra = 0;   // first piece of the pair that contains chunk0
             while (ra + 2 * w < k && chunk0 >= sst[ra + 2 * w]) ra += 2 * w;
@@ -791,17 +822,20 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             const int a1 = sst[(ra + w < k) ? ra + w : k];
             const int b1 = sst[(ra + 2 * w < k) ? ra + 2 * w : k];
             const int na = a1 - a0, nb = b1 - a1, diag = chunk0 - a0;
-            auto A = [&](int i) { return skey[pos16(a0 + i)]; };
-            auto Bf = [&](int j) { return skey[pos16(a1 + j)]; };
-            const int ai = merge_path32(A, na, Bf, nb, diag);
-            serial_merge<VT>(skey, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
+            moved = nb > 0;          // a run without a partner in this round (k not a power of two) stays where it is
+            if (moved) {
+                auto A = [&](int i) { return skey[pos16(a0 + i)]; };
+                auto Bf = [&](int j) { return skey[pos16(a1 + j)]; };
+                const int ai = merge_path32(A, na, Bf, nb, diag);
+                serial_merge<VT>(skey, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
 #pragma unroll
-            for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+                for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+            }
         }
         __syncthreads();
-        if (active) {
+        if (moved) {
 #pragma unroll
-            for (int i = 0; i < VT; ++i) { skey[pos16(chunk0 + i)] = kk[i]; sidx[pos16(chunk0 + i)] = ix[i]; }
+            for (int i = 0; i < VT; ++i) { skey[pos16(chunk0 + i)] = kk[i]; sidx[pos16(chunk0 + i)] = (IdxT)ix[i]; }
         }
         __syncthreads();
     }
@@ -854,7 +888,7 @@ __global__ __launch_bounds__(256) void k_bucket_merge(const double* __restrict__
             i64 gs = obase + rs[i], ge = obase + re[i];
             if (ext0 && v == vfirst) gs = sedge[0];
             if (ext1 && v == vlast) ge = sedge[3];
-            z[p * M + min(sidx[pos16(e)], (u32)(M - 1))] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
+            z[p * M + min((u32)sidx[pos16(e)], (u32)(M - 1))] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
@@ -933,21 +967,15 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
 // (`tail if tail > bulk else bulk`, src/mcmc_ref/diagnostics.py:40), NaN diagnostics when there
 // are fewer than two chains (diagnostics.py:29-30, 53-54, 69-70).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const double* __restrict__ X,
-                           i64 P, int C, double* __restrict__ res)
+__device__ __forceinline__ void finalize_param(const double* __restrict__ part, int S, i64 M,
+                                               const double* __restrict__ X, i64 P, int C, double* __restrict__ res, i64 p)
 {
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    double s1 = 0.0, s2 = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const double* o = part + (p * S + s) * 4;
-        s1 += o[0]; s2 += o[1]; b += o[2];
-    }
-    const double K = X[p * M], m = (double)M, mu = s1 / m;
-    double var = (s2 - s1 * mu) / m;
-    if (isinf(s2)) var = INFINITY;          // squares overflowed: inf like np.std, not inf - inf
+    double mu, m2, b, n;
+    merge_slice_moments(part + p * S * 4, S, mu, m2, b, n);
+    double var = m2 / (double)M;
+    if (isinf(m2)) var = INFINITY;          // squares overflowed: inf like np.std
     else if (!(var >= 0.0)) var = 0.0;
-    res[R_MEAN * P + p] = K + mu;
+    res[R_MEAN * P + p] = mu;
     res[R_STD * P + p] = sqrt(var);
     res[R_BAD * P + p] = b;
     if (C < 2) {
@@ -958,6 +986,16 @@ __global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const 
         const double rb = res[R_RHAT_BULK * P + p], rt = res[R_RHAT_TAIL * P + p];
         res[R_RHAT * P + p] = (rt > rb) ? rt : rb;
     }
+}
+
+// Stand-alone form: calls without diagnostics (Backend.stats only) and single-chain tensors.  With diagnostics the
+// same function runs inside k_diag_combine2 (one launch fewer per call).
+__global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const double* __restrict__ X,
+                           i64 P, int C, double* __restrict__ res)
+{
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    finalize_param(part, S, M, X, P, C, res, p);
 }
 
 // compare.compare_stats arithmetic (src/mcmc_ref/compare.py:41-43)
@@ -973,22 +1011,24 @@ __global__ void k_compare(const double* __restrict__ ref, const double* __restri
     pass[i] = (e <= tol) ? 1 : 0;
 }
 
-// Read-only streaming probe: what the HBM delivers to a kernel that does nothing but 16-byte loads (8 in flight per
-// lane).  bench.py reports it as `peak_measured` next to the 8 TB/s specification peak.
+// Read-only streaming probe: what the HBM delivers to a kernel that does nothing but 16-byte loads.  Each workgroup
+// streams a contiguous slice with 4 loads in flight per lane (the access pattern of k_moments_rows).  bench.py reports
+// the best rate over a few grid sizes as `peak_measured` next to the 8 TB/s specification peak.
 __global__ __launch_bounds__(256) void k_stream_read(const uint4* __restrict__ src, i64 nvec, u32* __restrict__ sink)
 {
-    const i64 stride = (i64)gridDim.x * 256;
-    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 per = (nvec + gridDim.x - 1) / gridDim.x;
+    const i64 b = (i64)blockIdx.x * per, e = (b + per < nvec) ? b + per : nvec;
     u32 acc = 0;
-    for (; i + 7 * stride < nvec; i += 8 * stride) {
-        uint4 r[8];
+    i64 i = b + threadIdx.x;
+    for (; i + 3 * 256 < e; i += 4 * 256) {
+        uint4 r[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = src[i + u * stride];
+        for (int u = 0; u < 4; ++u) r[u] = src[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
+        for (int u = 0; u < 4; ++u) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
     }
-    for (; i < nvec; i += stride) { const uint4 r = src[i]; acc ^= r.x ^ r.y ^ r.z ^ r.w; }
-    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;      // practically never: keeps the loads alive without a store stream
+    for (; i < e; i += 256) { const uint4 r = src[i]; acc ^= r.x ^ r.y ^ r.z ^ r.w; }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x & 1023] = acc;      // practically never: keeps the loads alive without a store stream
 }
 
 // Synthetic stress tensor: iid N(p, sigma_p), counter-based, layout [P][C][N].

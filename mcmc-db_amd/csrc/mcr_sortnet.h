@@ -1,4 +1,5 @@
-/* mcr_sortnet.h -- 16-input sorting network, 60 compare-exchanges in 10 layers.
+/* mcr_sortnet.h -- sorting networks for the per-lane register sort: 16 inputs (60 compare-exchanges in 10 layers)
+ * and 8 inputs (19 in 6).
  * Plain C so that the host-side test (tests/test_host_cpu.py) can verify it exhaustively with the
  * 0-1 principle (all 65536 binary inputs).  X(a, b) = compare-exchange positions a < b. */
 #ifndef MCR_SORTNET_H
@@ -14,4 +15,12 @@
     X(3, 5) X(6, 8) X(7, 9) X(10, 12)                                                     \
     X(3, 4) X(5, 6) X(7, 8) X(9, 10) X(11, 12)                                            \
     X(6, 7) X(8, 9)
+/* 8-input network, 19 compare-exchanges in 6 layers (the tile sort's 512-thread x 8-draw configuration). */
+#define MCR_NET8(X)                                                                        \
+    X(0, 2) X(1, 3) X(4, 6) X(5, 7)                                                        \
+    X(0, 4) X(1, 5) X(2, 6) X(3, 7)                                                        \
+    X(0, 1) X(2, 3) X(4, 5) X(6, 7)                                                        \
+    X(2, 4) X(3, 5)                                                                        \
+    X(1, 4) X(3, 6)                                                                        \
+    X(1, 2) X(3, 4) X(5, 6)
 #endif

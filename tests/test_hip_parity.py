@@ -256,8 +256,8 @@ def test_long_chains_merge_pass_path(ctx, oracle):
 
 
 def test_sticky_chains_continuation_paths(ctx, oracle):
-    """AR(1) with phi = 0.995: the first negative rho lies hundreds of lags out, so the flagged
-    continuation (lags 64..255) and the direct loop beyond it decide the truncation lag."""
+    """AR(1) with phi = 0.995: the first negative rho lies hundreds of lags out, so tier 2 (lags 64..255) and the
+    first tier-3 round beyond it decide the truncation lag."""
     rng = np.random.default_rng(17)
     C, N = 4, 6000
     x = np.empty((2, C, N))
@@ -272,6 +272,80 @@ def test_sticky_chains_continuation_paths(ctx, oracle):
     exp = oracle.summarize(x, "pcn")
     assert int(exp["lag_bulk"].max()) > 255, exp["lag_bulk"]
     check_summary(got, exp, what="sticky")
+
+
+def test_long_lag_tier3_random_walks(ctx, oracle):
+    """Truncation lags in the THOUSANDS: random walks and the provenance fake runner's ramps leave rho
+    positive for a large fraction of the chain, so tiers 1 and 2 (lags < 256) decide nothing and the chip-wide
+    rounds of k_acov_long / k_diag_long_scan do.  Lags exact, ESS to 1e-9; more listed
+    pairs (2 x 14) than the 16 slots of a launch; and the wall time of the
+    L ~ 6000 case, which one workgroup used to walk lag by lag (49 ms in round 1)."""
+    import time
+    rng = np.random.default_rng(5)
+    C, N = 4, 20000
+    x = np.cumsum(rng.normal(size=(14, C, N)), axis=2) * 0.01
+    x[12] = rng.normal(size=(C, N))                                   # an easy parameter among the sticky ones
+    x[13] = np.arange(C)[:, None] + 0.001 * np.arange(N)[None, :]     # generate.fake_jsonzip_runner's ramp
+    exp = oracle.summarize(x, "pcn")
+    got = ctx.summarize(x, "pcn")
+    check_summary(got, exp, what="tier3")
+    lags = np.concatenate([exp["lag_bulk"], exp["lag_tail"]])
+    assert (lags > 4096).sum() >= 4 and ((lags > 256) & (lags < 4096)).sum() >= 2, lags
+    one = np.ascontiguousarray(x[:1])
+    t = ctx.upload(one, "pcn")
+    try:
+        ctx.summarize(t)
+        t0 = time.perf_counter()
+        r = ctx.summarize(t)
+        ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        t.free()
+    assert int(r["lag_bulk"][0]) == int(exp["lag_bulk"][0])
+    print(f"\nrandom walk 4 x {N}, truncation lag {int(r['lag_bulk'][0])} / {int(r['lag_tail'][0])}: {ms:.2f} ms per call")
+    assert ms < 10.0, ms
+    # ragged chains through mcr_diagnose_chains: n = the shortest chain
+    chains = [list(np.cumsum(rng.normal(size=n)) * 0.01) for n in (5000, 4100, 6000, 4500)]
+    g, e = ctx.diagnose_chains(chains, 2), oracle.diag(chains, 2)
+    assert (g["lag_bulk"], g["lag_tail"]) == (e["lag_bulk"], e["lag_tail"]) and e["lag_bulk"] > 224
+    for k in ("rhat", "ess_bulk", "ess_tail"):
+        assert close(g[k], e[k], TIGHT), (k, g[k], e[k])
+
+
+def test_moments_with_an_outlying_first_draw(ctx, oracle):
+    """the moments used to be shifted by the parameter's FIRST draw in a single pass, so an unconverged
+    start (first draw d sigma away) cost d^2 eps of accuracy in std.  Now every tile / slice is two-pass around its
+    own mean and the pieces are merged with Chan's update: the reference's two-pass result (compare.py:58-64,
+    np.std) to 1e-12 whatever the first draw is."""
+    rng = np.random.default_rng(12)
+    x = rng.normal(size=(4, 4, 6000))
+    x[0, 0, 0] = 1e9                      # a single wild first draw
+    x[1, :, :200] += 1e7                  # an unconverged start of every chain
+    x[2] = x[2] * 1e-6 + 3.0              # small spread around an offset
+    x[3, 0, 0] = -1e12
+    exp = oracle.summarize(x, "pcn")
+    got = ctx.summarize(x, "pcn")
+    for p in range(4):
+        assert close(got["std"][p], exp["std"][p], 1e-12), (p, got["std"][p], exp["std"][p])
+        assert close(got["mean"][p], exp["mean"][p], 1e-12, scale=1e-12 * exp["std"][p]), p
+    t = ctx.upload(x, "pcn")
+    try:
+        mean, std = ctx.moments(t)                              # the streaming one-pass kernel (slice pivots + Chan)
+    finally:
+        t.free()
+    for p in range(4):
+        assert close(std[p], exp["std"][p], 1e-12), (p, std[p], exp["std"][p])
+    for p in range(4):
+        b = ctx.basic_stats(x[p].reshape(-1))
+        e = oracle.basic_stats(x[p].reshape(-1)) if hasattr(oracle, "basic_stats") else {"std": exp["std"][p]}
+        assert close(b["std"], e["std"], 1e-12), (p, b, e)
+    cnp = np.ascontiguousarray(np.transpose(x, (1, 2, 0)))      # strided variant (k_moments_cols)
+    t = ctx.upload(cnp, "cnp")
+    try:
+        _, std2 = ctx.moments(t)
+    finally:
+        t.free()
+    for p in range(4):
+        assert close(std2[p], exp["std"][p], 1e-12), (p, std2[p])
 
 
 def test_random_shapes_fuzz(ctx, oracle):

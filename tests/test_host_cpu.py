@@ -217,32 +217,37 @@ def test_param_block_and_id_file(monkeypatch, tmp_path):
 
 
 def test_sorting_network_is_a_sorting_network(tmp_path):
-    """0-1 principle: the 16-input network of csrc/mcr_sortnet.h sorts all 65536 binary inputs."""
+    """0-1 principle: the 16- and 8-input networks of csrc/mcr_sortnet.h sort all binary inputs."""
     import subprocess
     src = tmp_path / "check.c"
     src.write_text(r'''
 #include <stdio.h>
 #include "mcr_sortnet.h"
 #define X(a, b) {a, b},
-static const int net[][2] = { MCR_NET16(X) };
-int main(void) {
-    const int n = (int)(sizeof(net) / sizeof(net[0]));
+static const int net16[][2] = { MCR_NET16(X) };
+static const int net8[][2] = { MCR_NET8(X) };
+static long check(const int (*net)[2], int n, int w) {
     long bad = 0;
-    for (unsigned m = 0; m < 65536u; ++m) {
+    for (unsigned m = 0; m < (1u << w); ++m) {
         int v[16];
-        for (int i = 0; i < 16; ++i) v[i] = (m >> i) & 1;
-        for (int c = 0; c < n; ++c) { int a = net[c][0], b = net[c][1]; if (a >= b) return 3;
+        for (int i = 0; i < w; ++i) v[i] = (m >> i) & 1;
+        for (int c = 0; c < n; ++c) { int a = net[c][0], b = net[c][1]; if (a >= b || b >= w) return -1;
             if (v[b] < v[a]) { int t = v[a]; v[a] = v[b]; v[b] = t; } }
-        for (int i = 0; i < 15; ++i) if (v[i] > v[i + 1]) { ++bad; break; }
+        for (int i = 0; i + 1 < w; ++i) if (v[i] > v[i + 1]) { ++bad; break; }
     }
-    printf("%d %ld\n", n, bad);
-    return bad != 0;
+    return bad;
+}
+int main(void) {
+    const int n16 = (int)(sizeof(net16) / sizeof(net16[0])), n8 = (int)(sizeof(net8) / sizeof(net8[0]));
+    const long b16 = check(net16, n16, 16), b8 = check(net8, n8, 8);
+    printf("%d %ld %d %ld\n", n16, b16, n8, b8);
+    return b16 != 0 || b8 != 0;
 }
 ''')
     exe = tmp_path / "check"
     subprocess.run(["gcc", "-O2", "-I", str(ROOT / "mcmc-db_amd" / "csrc"), "-o", str(exe), str(src)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert out == ["60", "0"]
+    assert out == ["60", "0", "19", "0"]
 
 
 def test_store_layout_and_precedence(tmp_path):
