@@ -187,8 +187,11 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
                    double* ks, double* w1);
 /* Population covariance matrix (ddof = 0, like compare.py:63) of P parameters over M pooled draws,
  * draws[P][M] host row-major -> cov[P][P].  The one dense contraction of the path: fp64 MFMA
- * (v_mfma_f64_16x16x4f64), split over the draw axis.  numpy.cov(x, ddof=0).  SURVEY.md row X3. */
+ * (v_mfma_f64_16x16x4f64; LDS-staged 64 x 64 tiles, upper triangle, split over the draw axis).
+ * numpy.cov(x, ddof=0).  SURVEY.md row X3. */
 int mcr_covariance(mcr_ctx* ctx, const double* draws, int64_t M, int64_t P, double* cov);
+/* The same on device-resident buffers of this ctx (draws_dev [P][M], cov_dev [P][P]); P <= 8192. */
+int mcr_covariance_dev(mcr_ctx* ctx, const double* draws_dev, int64_t M, int64_t P, double* cov_dev);
 
 /* ---- measurement ------------------------------------------------------------------- */
 /* When on, every kernel launch is bracketed by HIP events on the ctx stream. */

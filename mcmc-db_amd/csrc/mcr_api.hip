@@ -40,13 +40,13 @@ constexpr int kMaxGridY = 65535;
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_ACOV_LONG, K_DIAG_LONG, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_ACOV_LONG, K_DIAG_LONG, K_COV_FINAL, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_splitters",
     "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable",
-    "k_pq_snappy", "k_pq_decode", "k_gather_rows", "k_acov_long", "k_diag_long_scan"};
+    "k_pq_snappy", "k_pq_decode", "k_gather_rows", "k_acov_long", "k_diag_long_scan", "k_cov_final"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -319,7 +319,8 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
 }
 
 struct PipeIn {
-    const double* X;     // [pc][M] f64 contiguous (user tensor or ingest buffer)
+    const void* X;       // [pc][M] contiguous: f64 (user tensor or ingest buffer) or, x_f32, the user's f32 tensor itself
+    bool x_f32 = false;
     i64 M, pc;
     int C;
     const i64* d_off;
@@ -385,7 +386,7 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
            (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB, a.long_count, a.long_list,   // kA / kB: the sort's key buffers, free by now
-           (const double*)a.part, (int)a.ntiles, a.X);
+           (const double*)a.part, (int)a.ntiles);
     // tier 3 for the pairs still undecided at lag 256: rounds [256, 16384), [16384, 262144), ... over the whole chip
     // (chains of up to 16384 draws: ONE round, i.e. two near-empty launches when no pair is listed)
     const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
@@ -416,9 +417,14 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     // (the z lookup table of this M comes from the context's cache: get_ztab)
     // 1. tile sort (+ moment partials, + regular samples when a tile is already a run)
     const bool bucket = a.bk_B > 0;
-    LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<TNT, TVT, IdxT>), dim3((unsigned)a.ntiles, py), dim3(TNT),
-           lds_tile, a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles,
-           (bucket && a.bk_R == kTile) ? a.samp : (double*)nullptr);
+    double* const samp1 = (bucket && a.bk_R == kTile) ? a.samp : (double*)nullptr;
+    if (a.x_f32) {
+        LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<TNT, TVT, IdxT, float>), dim3((unsigned)a.ntiles, py), dim3(TNT),
+               lds_tile, (const float*)a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles, samp1);
+    } else {
+        LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<TNT, TVT, IdxT, double>), dim3((unsigned)a.ntiles, py), dim3(TNT),
+               lds_tile, (const double*)a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles, samp1);
+    }
     double *kin = a.kA, *kout = a.kB;
     IdxT *iin = (IdxT*)a.iA, *iout = (IdxT*)a.iB;
     const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
@@ -531,7 +537,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
     }
     // 8. finalize (calls without diagnostics, single chains)
     LAUNCH(ctx, K_FINALIZE, k_finalize, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0, (const double*)a.part,
-           (int)a.ntiles, M, a.X, pc, (a.do_diag ? a.C : 0), a.d_res);
+           (int)a.ntiles, M, pc, (a.do_diag ? a.C : 0), a.d_res);
     return MCR_OK;
 }
 
@@ -647,7 +653,9 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     s.chunks.clear();
     s.trivial_nan = (M == 0 || P == 0);
     if (!s.trivial_nan) {
-        const bool ingest = !(dtype == MCR_F64 && (N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
+        // tensors in the Arrow column layout [P][C][N] are consumed in place, f64 and f32 alike (the tile sort widens f32
+        // as it loads); anything else goes through one ingest pass into X[P][M] f64
+        const bool ingest = !((N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
         const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
         const size_t slack = 40 * 256;
         if (wp.per_param + slack > ctx->ws_limit)
@@ -706,7 +714,9 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     if (r2) return r2;
                     a.X = X;
                 } else {
-                    a.X = reinterpret_cast<const double*>(draws_dev) + p0 * M;
+                    a.x_f32 = dtype == MCR_F32;
+                    a.X = a.x_f32 ? (const void*)(reinterpret_cast<const float*>(draws_dev) + p0 * M)
+                                  : (const void*)(reinterpret_cast<const double*>(draws_dev) + p0 * M);
                 }
                 const size_t res_off = (size_t)R * (size_t)p0;
                 a.d_res = s.d_res + res_off;
@@ -1343,44 +1353,67 @@ int mcr_two_sample(mcr_ctx* ctx, const double* ref, int64_t Mr, const double* ac
     return MCR_OK;
 }
 
+// Device-resident form (draws_dev [P][M] f64, cov_dev [P][P] f64, both in this context's device memory): what
+// tools/cov_bench.py times.  Synchronous.
+int mcr_covariance_dev(mcr_ctx* ctx, const double* draws_dev, int64_t M, int64_t P, double* cov_dev)
+{
+    if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
+    if (P < 0 || M < 1 || (P > 0 && (!draws_dev || !cov_dev))) return fail(ctx, MCR_EINVAL, "bad argument");
+    if (P == 0) return MCR_OK;
+    if (P > 8192) return fail(ctx, MCR_EINVAL, "P > 8192 not supported by mcr_covariance");
+    if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_covariance with summaries in flight");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nb = (int)((P + kCovBM - 1) / kCovBM);
+    const i64 P64 = (i64)nb * kCovBM;
+    const i64 tiles = (i64)nb * (nb + 1) / 2;                        // workgroups that do work per draw slice
+    int ksplit = (int)((1024 + tiles - 1) / tiles);                  // >= ~1024 workgroups: 2 per CU, two rounds
+    const i64 maxsplit = (M + 8 * kCovBK - 1) / (8 * kCovBK);        // a slice is at least 8 panels long
+    if (ksplit > maxsplit) ksplit = (int)maxsplit;
+    if (ksplit < 1) ksplit = 1;
+    i64 kchunk = (M + ksplit - 1) / ksplit;
+    kchunk = (kchunk + kCovBK - 1) / kCovBK * kCovBK;
+    ksplit = (int)((M + kchunk - 1) / kchunk);
+    const int S = 8;
+    const size_t need = (size_t)ksplit * P64 * P64 * 8 + (size_t)P * (S * 32 + 16) + 16 * 256;
+    int rc = ensure_ws(ctx, need);
+    if (rc) return rc;
+    Carve cv{reinterpret_cast<char*>(ctx->ws)};
+    double* partial = cv.take<double>((size_t)ksplit * P64 * P64);
+    double* mpart = cv.take<double>((size_t)P * S * 4);
+    double* d_mean = cv.take<double>((size_t)P);
+    double* d_std = cv.take<double>((size_t)P);
+    rc = moments_impl<double>(ctx, draws_dev, 1, M, P, M, 1, M, d_mean, d_std, mpart, (M >= 8 * 2048) ? S : 1, true);
+    if (rc) return rc;
+    if ((M & 1) == 0 && (reinterpret_cast<uintptr_t>(draws_dev) & 15) == 0) {
+        LAUNCH(ctx, K_COV, (k_cov_mfma<true>), dim3((unsigned)(nb * nb), (unsigned)ksplit), dim3(256), 0, draws_dev,
+               (const double*)d_mean, (i64)M, (i64)P, nb, kchunk, partial);
+    } else {
+        LAUNCH(ctx, K_COV, (k_cov_mfma<false>), dim3((unsigned)(nb * nb), (unsigned)ksplit), dim3(256), 0, draws_dev,
+               (const double*)d_mean, (i64)M, (i64)P, nb, kchunk, partial);
+    }
+    LAUNCH(ctx, K_COV_FINAL, k_cov_final, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, (const double*)partial,
+           ksplit, nb, (i64)M, (i64)P, cov_dev);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    return MCR_OK;
+}
+
 int mcr_covariance(mcr_ctx* ctx, const double* draws, int64_t M, int64_t P, double* cov)
 {
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
     if (P < 0 || M < 1 || (P > 0 && (!draws || !cov))) return fail(ctx, MCR_EINVAL, "bad argument");
     if (P == 0) return MCR_OK;
-    if (P > 4096) return fail(ctx, MCR_EINVAL, "P > 4096 not supported by mcr_covariance");
     if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_covariance with summaries in flight");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int tiles = (int)((P + 15) / 16);
-    const i64 P16 = (i64)tiles * 16;
-    int ksplit = (int)((2048 + (i64)tiles * tiles - 1) / ((i64)tiles * tiles));   // >= ~2048 waves in flight
-    const i64 maxsplit = (M + 255) / 256;
-    if (ksplit > maxsplit) ksplit = (int)maxsplit;
-    if (ksplit < 1) ksplit = 1;
-    i64 kchunk = (M + ksplit - 1) / ksplit;
-    kchunk = (kchunk + 3) / 4 * 4;
-    ksplit = (int)((M + kchunk - 1) / kchunk);
-    const int S = 8;
-    const size_t need = (size_t)P * M * 8 + (size_t)ksplit * P16 * P16 * 8 + (size_t)P * P * 8 + (size_t)P * (S * 32 + 16) + 16 * 256;
-    int rc = ensure_ws(ctx, need);
+    int rc = ensure_stage(ctx, (size_t)P * M * 8 + (size_t)P * P * 8 + 256);
     if (rc) return rc;
-    Carve cv{reinterpret_cast<char*>(ctx->ws)};
-    double* X = cv.take<double>((size_t)P * M);
-    double* partial = cv.take<double>((size_t)ksplit * P16 * P16);
-    double* d_cov = cv.take<double>((size_t)P * P);
-    double* mpart = cv.take<double>((size_t)P * S * 4);
-    double* d_mean = cv.take<double>((size_t)P);
-    double* d_std = cv.take<double>((size_t)P);
+    double* X = (double*)ctx->stage;
+    double* d_cov = (double*)((char*)ctx->stage + align_up((size_t)P * M * 8, 256));
     HIP_TRY(ctx, hipMemcpyAsync(X, draws, sizeof(double) * (size_t)P * M, hipMemcpyHostToDevice, ctx->stream));
-    rc = moments_impl<double>(ctx, X, 1, M, P, M, 1, M, d_mean, d_std, mpart, (M >= 8 * 2048) ? S : 1, true);
+    rc = mcr_covariance_dev(ctx, X, M, P, d_cov);
     if (rc) return rc;
-    LAUNCH(ctx, K_COV, k_cov_mfma, dim3((unsigned)(tiles * tiles), (unsigned)ksplit), dim3(64), 0, (const double*)X,
-           (i64)M, (i64)P, tiles, kchunk, partial);
-    LAUNCH(ctx, K_COV, k_cov_final, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, (const double*)partial,
-           ksplit, tiles, (const double*)X, (i64)M, (i64)P, (const double*)d_mean, d_cov);
     HIP_TRY(ctx, hipMemcpyAsync(cov, d_cov, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    prof_resolve(ctx);
     return MCR_OK;
 }
 

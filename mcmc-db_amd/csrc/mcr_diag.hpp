@@ -409,15 +409,14 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
                                                        double* __restrict__ res, i64 P,
                                                        double* __restrict__ dev_b, double* __restrict__ dev_t,
                                                        unsigned* __restrict__ long_count, unsigned* __restrict__ long_list,
-                                                       const double* __restrict__ part, int ntiles,
-                                                       const double* __restrict__ X)
+                                                       const double* __restrict__ part, int ntiles)
 {
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
     // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
     // k_finalize, done here by the first thread of the parameter's first workgroup
-    if (kind == 0 && threadIdx.x == 0) finalize_param(part, ntiles, M, X, P, C, res, p);
+    if (kind == 0 && threadIdx.x == 0) finalize_param(part, ntiles, M, P, C, res, p);
     if (more[pk] == 0u) return;
     __shared__ double ctl[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -320,8 +320,8 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
 // serial_merge lands on sidx[0] (in bounds, value never selected); the reduction scratch reuses skey at the end.
 template <typename IdxT> constexpr size_t sort_lds_bytes(int T) { return (size_t)T * (8 + sizeof(IdxT)); }
 
-template <int NT, int VT, typename IdxT>
-__global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, i64 M,
+template <int NT, int VT, typename IdxT, typename XT>
+__global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 M,
                                                   double* __restrict__ keys, IdxT* __restrict__ idx,
                                                   double* __restrict__ part, int ntiles,
                                                   double* __restrict__ samp)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
     const i64 p = blockIdx.y;
     const i64 base = (i64)tile * T;
     const int count = (int)((M - base < (i64)T) ? M - base : (i64)T);
-    const double* src = X + p * M + base;
+    const XT* src = X + p * M + base;    // XT = float: f32 tensors in the Arrow layout are widened here, not by an ingest pass
 
     double bad = 0.0;
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const double* __restrict__ X, 
         const int e = i * NT + tid;
         double v = INFINITY;
         if (e < count) {
-            v = src[e];
+            v = (double)src[e];
             bad += isfinite(v) ? 0.0 : 1.0;
         }
         skey[pos16(e)] = v;
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256) void k_rank_z(const double* __restrict__ keys,
 // are fewer than two chains (diagnostics.py:29-30, 53-54, 69-70).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void finalize_param(const double* __restrict__ part, int S, i64 M,
-                                               const double* __restrict__ X, i64 P, int C, double* __restrict__ res, i64 p)
+                                               i64 P, int C, double* __restrict__ res, i64 p)
 {
     double mu, m2, b, n;
     merge_slice_moments(part + p * S * 4, S, mu, m2, b, n);
@@ -990,12 +990,11 @@ __device__ __forceinline__ void finalize_param(const double* __restrict__ part, 
 
 // Stand-alone form: calls without diagnostics (Backend.stats only) and single-chain tensors.  With diagnostics the
 // same function runs inside k_diag_combine2 (one launch fewer per call).
-__global__ void k_finalize(const double* __restrict__ part, int S, i64 M, const double* __restrict__ X,
-                           i64 P, int C, double* __restrict__ res)
+__global__ void k_finalize(const double* __restrict__ part, int S, i64 M, i64 P, int C, double* __restrict__ res)
 {
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    finalize_param(part, S, M, X, P, C, res, p);
+    finalize_param(part, S, M, P, C, res, p);
 }
 
 // compare.compare_stats arithmetic (src/mcmc_ref/compare.py:41-43)

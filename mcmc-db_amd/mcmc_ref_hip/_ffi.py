@@ -90,6 +90,7 @@ SYMBOLS = {
     "mcr_compare": (C.c_int, [C.c_void_p, _dp, _dp, _I64, C.c_double, _dp, C.POINTER(C.c_uint8)]),
     "mcr_two_sample": (C.c_int, [C.c_void_p, _dp, _I64, _dp, _I64, _I64, _dp, _dp]),
     "mcr_covariance": (C.c_int, [C.c_void_p, _dp, _I64, _I64, _dp]),
+    "mcr_covariance_dev": (C.c_int, [C.c_void_p, C.c_void_p, _I64, _I64, C.c_void_p]),
     "mcr_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mcr_profile_reset": (C.c_int, [C.c_void_p]),
     "mcr_profile_get": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]),

@@ -52,7 +52,7 @@ def test_two_sample_matches_scipy(ctx):
 
 def test_covariance_mfma_matches_numpy(ctx):
     rng = np.random.default_rng(5)
-    for P, M in [(1, 10), (5, 1000), (16, 4096), (33, 10001), (100, 40000)]:
+    for P, M in [(1, 10), (5, 1000), (16, 4096), (33, 10001), (65, 77), (130, 3001), (100, 40000)]:
         L = rng.normal(size=(P, P))
         x = (L @ rng.normal(size=(P, M))) * 1e-2 + rng.normal(size=(P, 1)) * 50.0   # correlated, offset means
         cov = ctx.covariance(x)

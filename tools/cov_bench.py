@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""fp64 MFMA covariance (extension X3): achieved TFLOP/s of k_cov_mfma against the dense-fp64 matrix peak.
+
+    python tools/cov_bench.py [--out gpurun_out/cov.json]
+
+FLOPs counted = 2 * P^2 * M (the full Gram matrix a dense SYRK is priced at); the kernel computes only the block
+upper triangle, so `useful_fraction` says how much of that count it really executes.  Peak: 78.6 TFLOP/s
+(256 CUs x 4 SIMDs x 32 fp64 FMA per clock x 2.4 GHz; MI355X spec fp64 matrix = fp64 vector rate).
+Parity unpinned by the reference (no covariance there): the result is checked against numpy.cov(ddof=0)."""
+import argparse, json, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
+from mcmc_ref_hip import _ffi
+
+PEAK_TF = 78.6
+ap = argparse.ArgumentParser()
+ap.add_argument("--out", default=None)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+ctx = _ffi.Context(0)
+rows = []
+for P, M in ((100, 40000), (1000, 40000), (2048, 40000), (4096, 20000)):
+    rng = np.random.default_rng(P)
+    x = rng.normal(size=(P, M)) * (1.0 + np.arange(P)[:, None] % 7) + np.arange(P)[:, None]
+    dx = _ffi.DeviceBuffer(ctx, x.nbytes).upload(x)
+    dc = _ffi.DeviceBuffer(ctx, P * P * 8)
+    call = lambda: ctx._check(ctx.lib.mcr_covariance_dev(ctx.handle, dx.ptr, M, P, dc.ptr))
+    call()
+    cov = dc.download(np.float64, P * P).reshape(P, P)
+    exp = np.cov(x, ddof=0) if P <= 1000 else None
+    err = float(np.max(np.abs(cov - exp)) / np.max(np.abs(exp))) if exp is not None else None
+    ctx.profile(True); ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        call()
+    wall = (time.perf_counter() - t0) / a.reps
+    pr = ctx.profile_get(); ctx.profile(False)
+    kms = pr["k_cov_mfma"]["total_ms"] / pr["k_cov_mfma"]["launches"]
+    nb = (P + 63) // 64
+    flops = 2.0 * P * P * M
+    rows.append({"P": P, "M": M, "kernel_ms": kms, "call_ms": wall * 1e3, "TFLOPs": flops / (kms * 1e-3) / 1e12,
+                 "frac_of_peak": flops / (kms * 1e-3) / 1e12 / PEAK_TF,
+                 "useful_fraction": (nb * (nb + 1) / 2 * 64 * 64) / float(P * P), "max_rel_err_vs_numpy": err,
+                 "other_kernels_ms": {k: v["total_ms"] / v["launches"] for k, v in pr.items() if k != "k_cov_mfma"}})
+    print(json.dumps(rows[-1]), flush=True)
+    dx.free(); dc.free()
+out = {"kernel": "k_cov_mfma (v_mfma_f64_16x16x4f64, 64x64 tiles, LDS-staged, double-buffered)", "peak_TFLOPs": PEAK_TF, "rows": rows}
+if a.out:
+    Path(a.out).write_text(json.dumps(out, indent=1) + "\n")
+ctx.close()

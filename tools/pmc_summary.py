@@ -22,6 +22,8 @@ def per_kernel(path, counter):
             name = m.group(1)
             if name == "k_merge":
                 name = "k_fold_merge" if "true" in (m.group(2) or "") else "k_merge"
+            if name == "k_diag_long_scan":
+                name = "k_diag_long_scan"
             if name == "k_acov_seg":
                 name = "k_acov_seg" if "true" in (m.group(2) or "") else "k_acov_more"
             if name == "k_diag_combine":
