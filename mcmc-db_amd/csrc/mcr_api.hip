@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "mcr_kernels.hpp"
+#include "mcr_sort32.hpp"
 #include "mcr_diag.hpp"
 #include "mcr_ext.hpp"
 #include "mcr_parquet.hpp"
@@ -110,6 +111,7 @@ struct mcr_ctx {
     // hipGraph cache: the launch sequence of one summarize call is static for a given shape,
     // buffer set and slot, so it is captured once and replayed (removes ~5 us of host launch gap
     // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
+    bool f32_records = true; // MCR_F32_RECORDS=0: f32 tensors take the f64 kernels (widened by the tile sort) instead of mcr_sort32.hpp
     int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
     bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
     std::vector<GraphEntry> graphs;
@@ -321,6 +323,7 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
 struct PipeIn {
     const void* X;       // [pc][M] contiguous: f64 (user tensor or ingest buffer) or, x_f32, the user's f32 tensor itself
     bool x_f32 = false;
+    bool no_records = false;   // MCR_F32_RECORDS=0: keep f32 tensors on the f64 kernels (A/B measurements, parity tests)
     i64 M, pc;
     int C;
     const i64* d_off;
@@ -441,14 +444,14 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     if (bucket) {
         // 3. exact k-way partition + in-LDS bucket merge, fused with ranks -> z
         if (a.bk_R != kTile)
-            LAUNCH(ctx, K_SPLITTERS, k_sample_runs, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const double*)kin, M,
+            LAUNCH(ctx, K_SPLITTERS, k_sample_runs<double>, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const double*)kin, M,
                    a.bk_R, a.samp);
         const int S = a.bk_k * (int)(a.bk_R / 64);
         const size_t lds_spl = (size_t)S * 12 + (size_t)(a.bk_B + 1) * 16 + (size_t)(a.bk_B + 1) * a.bk_k * 4 + 64;
         if (lds_spl > 60 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters),
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters<double>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
-        LAUNCH(ctx, K_SPLITTERS, k_splitters, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
+        LAUNCH(ctx, K_SPLITTERS, k_splitters<double>, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
                M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile + 512,
@@ -463,12 +466,69 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
 }
 
 template <typename IdxT, int NT, int VT>
+int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
+{
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT, u64>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + 256,
+           (const u64*)kin, (const IdxT*)nullptr, (double*)nullptr, (IdxT*)nullptr, a.M, (i64)0, (const double*)a.d_res, a.pc,
+           (const i64*)a.split, a.zt);
+    return MCR_OK;
+}
+
+template <typename IdxT, int NT, int VT>
 int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
 {
     LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + 256,
            (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, (const double*)a.d_res, a.pc,
            (const i64*)a.split, a.zt);
     return MCR_OK;
+}
+
+// f32 tensors (Arrow layout, bucket path): the same stage on packed (key, position) records (mcr_sort32.hpp).  The
+// record arrays live in the f64 key buffers kA / kB (8 bytes per draw); the position buffers stay unused.
+template <int TNT, int TVT, int MNT, int MVT>
+int sort_stage_rec(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
+{
+    static_assert(TNT * TVT == kTile && MNT * MVT == kTile, "tile geometry");
+    const i64 M = a.M, pc = a.pc;
+    const unsigned py = (unsigned)pc;
+    u64 *rin = reinterpret_cast<u64*>(a.kA), *rout = reinterpret_cast<u64*>(a.kB);
+    LAUNCH(ctx, K_TILE_SORT, (k_tile_sort32<TNT, TVT>), dim3((unsigned)a.ntiles, py), dim3(TNT), (size_t)kTile * 8,
+           (const float*)a.X, M, rin, a.part, (int)a.ntiles, (a.bk_R == kTile) ? a.samp : (double*)nullptr);
+    const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
+    for (i64 R = kTile; R < a.bk_R; R *= 2) {
+        LAUNCH(ctx, K_MERGE, (k_merge32<MNT, MVT>), dim3(nblk, py), dim3(MNT), rec_lds_bytes(kTile), (const u64*)rin, rout, M, R);
+        std::swap(rin, rout);
+    }
+    if (a.bk_R != kTile)
+        LAUNCH(ctx, K_SPLITTERS, k_sample_runs<u64>, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const u64*)rin, M, a.bk_R, a.samp);
+    const int S = a.bk_k * (int)(a.bk_R / 64);
+    const size_t lds_spl = (size_t)S * 12 + (size_t)(a.bk_B + 1) * 16 + (size_t)(a.bk_B + 1) * a.bk_k * 4 + 64;
+    if (lds_spl > 60 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters<u64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
+    LAUNCH(ctx, K_SPLITTERS, k_splitters<u64>, dim3(py), dim3(1024), lds_spl, (const u64*)rin, (const double*)a.samp,
+           M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
+    const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);
+    LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge32<MNT, MVT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), rec_lds_bytes(kTile) + 512,
+           (const u64*)rin, rout, M, a.bk_k, a.bk_B, (const u32*)a.cut, (const u32*)a.boff,
+           a.do_diag ? a.zb : (u32*)nullptr, pc, a.bk_R);
+    std::swap(rin, rout);
+    *kin_o = reinterpret_cast<double*>(rin); *kout_o = reinterpret_cast<double*>(rout);
+    *iin_o = a.iA; *iout_o = a.iB; *ranked_o = true;
+    return MCR_OK;
+}
+
+int sort_stage_rec_i(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
+{
+    const int t = ctx->sort_cfg % 10, m = ctx->sort_cfg / 10;
+    if (t == 0) {
+        if (m == 0) return sort_stage_rec<256, 16, 256, 16>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+        if (m == 1) return sort_stage_rec<256, 16, 512, 8>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+        return sort_stage_rec<256, 16, 1024, 4>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    }
+    if (m == 0) return sort_stage_rec<512, 8, 256, 16>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    if (m == 1) return sort_stage_rec<512, 8, 512, 8>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
+    return sort_stage_rec<512, 8, 1024, 4>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
 }
 
 // MCR_SORT_CFG = tile + 10 * merge.  tile: 0 = 256 lanes x 16 draws, 1 = 512 x 8.  merge: 0 = 256 x 16, 1 = 512 x 8,
@@ -489,8 +549,13 @@ int sort_stage_i(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     return sort_stage_t<IdxT, 512, 8, 1024, 4>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
 }
 
+// Records are used for f32 tensors whenever the bucket partition applies (pooled arrays up to 512 K draws); beyond
+// that the tile sort widens the f32 draws itself and the f64 kernels run.
+inline bool use_records(const PipeIn& a) { return a.x_f32 && a.bk_B > 0 && !a.no_records; }
+
 int sort_stage(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double** kout_o, void** iout_o, bool* ranked_o)
 {
+    if (use_records(a)) return sort_stage_rec_i(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
     return a.M <= kIdx16Max ? sort_stage_i<unsigned short>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o)
                             : sort_stage_i<u32>(ctx, a, kin_o, iin_o, kout_o, iout_o, ranked_o);
 }
@@ -499,6 +564,11 @@ template <typename IdxT>
 int fold_stage_i(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
 {
     const int m = ctx->sort_cfg / 10;
+    if (use_records(a)) {
+        if (m == 0) return launch_fold_rec<IdxT, 256, 16>(ctx, a, kin, fgrid);
+        if (m == 1) return launch_fold_rec<IdxT, 512, 8>(ctx, a, kin, fgrid);
+        return launch_fold_rec<IdxT, 1024, 4>(ctx, a, kin, fgrid);
+    }
     if (m == 0) return launch_fold<IdxT, 256, 16>(ctx, a, kin, iin, kout, iout, fgrid);
     if (m == 1) return launch_fold<IdxT, 512, 8>(ctx, a, kin, iin, kout, iout, fgrid);
     return launch_fold<IdxT, 1024, 4>(ctx, a, kin, iin, kout, iout, fgrid);
@@ -518,8 +588,13 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         if (rc) return rc;
     }
     // 3. order statistics
-    LAUNCH(ctx, K_ORDER_STATS, k_order_stats, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
-           (const double*)kin, M, pc, a.q, a.d_res, a.split);
+    if (use_records(a)) {
+        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
+               (const u64*)kin, M, pc, a.q, a.d_res, a.split);
+    } else {
+        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<double>, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
+               (const double*)kin, M, pc, a.q, a.d_res, a.split);
+    }
     if (a.do_diag) {
         // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)
         if (!ranked)
@@ -715,6 +790,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.X = X;
                 } else {
                     a.x_f32 = dtype == MCR_F32;
+                    a.no_records = !ctx->f32_records;
                     a.X = a.x_f32 ? (const void*)(reinterpret_cast<const float*>(draws_dev) + p0 * M)
                                   : (const void*)(reinterpret_cast<const double*>(draws_dev) + p0 * M);
                 }
@@ -899,6 +975,7 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_WORKSPACE_MB")) { const long v = atol(env); if (v > 0) mb = (size_t)v; }
     ctx->ws_limit = mb << 20;
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
+    if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
     if (const char* env = getenv("MCR_SORT_CFG")) {
         const int v = atoi(env);
         if (v >= 0 && v % 10 <= 1 && v / 10 <= 2) ctx->sort_cfg = v;

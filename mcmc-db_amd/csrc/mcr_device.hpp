@@ -95,7 +95,7 @@ __device__ __forceinline__ i64 merge_path(FA a, i64 na, FB b, i64 nb, i64 diag)
     i64 hi = diag < na ? diag : na;
     while (lo < hi) {
         i64 mid = (lo + hi) >> 1;
-        double ak = a(mid), bk = b(diag - 1 - mid);
+        const auto ak = a(mid), bk = b(diag - 1 - mid);
         if (!(bk < ak)) lo = mid + 1; else hi = mid;
     }
     return lo;
@@ -110,7 +110,7 @@ __device__ __forceinline__ int merge_path32(FA a, int na, FB b, int nb, int diag
     int hi = diag < na ? diag : na;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const double ak = a(mid), bk = b(diag - 1 - mid);
+        const auto ak = a(mid), bk = b(diag - 1 - mid);      // doubles, or packed (key, position) records
         const bool right = !(bk < ak);
         lo = right ? mid + 1 : lo;
         hi = right ? hi : mid;
@@ -149,6 +149,27 @@ __device__ __forceinline__ i64 merge_path_wave(FA a, i64 na, FB b, i64 nb, i64 d
 // consecutive elements still occupies its own 16 slots.  One instruction cheaper per access than the pad slot per
 // 16 elements it replaced (arrays are still sized for that padding).
 __device__ __forceinline__ int pos16(int e) { return e ^ ((e >> 4) & 15); }
+
+// ---- f32 draws as packed sort records ------------------------------------------------------------
+// A record is (order-preserving 32-bit image of the float) << 32 | pooled position: ONE 64-bit integer compare orders
+// (value, position), one 8-byte LDS slot holds key and payload, and the widened f64 value -- all the statistics are
+// computed on -- is recovered exactly from the key.  -0.0f is mapped onto +0.0f first (they tie, as in Python).
+__device__ __forceinline__ u32 f32_key(float x)
+{
+    u32 b = __float_as_uint(x);
+    if (x == 0.0f) b = 0u;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ double key_value(u32 k)
+{
+    const u32 b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return (double)__uint_as_float(b);
+}
+constexpr u64 kRecPad = ~0ull;      // sorts behind every real record (a NaN's key is below 0xFFFFFFFF)
+
+// Element i of a sorted key array as the f64 value the statistics use: plain doubles, or f32 records.
+__device__ __forceinline__ double sorted_key(const double* a, i64 i) { return a[i]; }
+__device__ __forceinline__ double sorted_key(const u64* a, i64 i) { return key_value((u32)(a[i] >> 32)); }
 
 // ---- counter-based generator (bench / stress tensor) ------------------------------------------
 __host__ __device__ __forceinline__ u64 splitmix64(u64 x)

@@ -423,20 +423,19 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
 // Tie runs of a sorted LDS array by scans instead of per-element searches (uniform cost however heavy
 // the ties): thread t owns positions [16t, 16t+16); rs[i] / re[i] = block-local [start, end) of the
 // run of equal keys containing position 16t+i.  `wsh` = 2 * NT/64 ints of LDS scratch.
-template <int NT, int VT>
-__device__ __forceinline__ void block_tie_runs(const double* skey, int total, int* wsh, int (&rs)[VT],
-                                               int (&re)[VT])
+template <int NT, int VT, class KF>
+__device__ __forceinline__ void block_tie_runs(KF key_at, int total, int* wsh, int (&rs)[VT], int (&re)[VT])
 {
     constexpr int NW = NT / kWave;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int base = tid * VT;
     bool h[VT];
-    double prev = (base > 0 && base - 1 < total) ? skey[pos16(base - 1)] : 0.0;
+    auto prev = key_at((base > 0 && base - 1 < total) ? base - 1 : 0);     // (position 0 is a head whatever it compares to)
     int cur = -1, first = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         const int g = base + i;
-        const double kv = (g < total) ? skey[pos16(g)] : 0.0;
+        const auto kv = key_at(g < total ? g : 0);
         h[i] = (g == 0) || (g >= total) || (prev != kv);
         if (h[i]) { cur = g; if (first == 0x7fffffff) first = g; }
         rs[i] = cur;
@@ -481,8 +480,10 @@ __device__ __forceinline__ void block_tie_runs(const double* skey, int total, in
 // rounding is monotone), against the values at or above it (x - med).  This replaces the second
 // full sort of src/mcmc_ref/diagnostics.py:93-98 + :110.  Each workgroup owns OB = NT*VT outputs.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int VT, bool FOLD, typename IdxT>
-__global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, const IdxT* __restrict__ iin,
+// KT = double: sorted keys in `kin`, positions in `iin`.  KT = u64 (FOLD only): sorted f32 records in `kin`
+// (mcr_sort32.hpp), `iin` unused -- the fold step widens the keys on the fly, its own keys |x - med| are f64.
+template <int NT, int VT, bool FOLD, typename IdxT, typename KT = double>
+__global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const IdxT* __restrict__ iin,
                                               double* __restrict__ kout, IdxT* __restrict__ iout, i64 M,
                                               i64 R, const double* __restrict__ res, i64 P,
                                               const i64* __restrict__ split, u32* __restrict__ z)
@@ -501,8 +502,12 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     }
     const i64 o0 = (i64)blk * OB;
     if (o0 >= M) return;
-    const double* kp = kin + p * M;
+    const KT* kp = kin + p * M;
     const IdxT* ip = iin + p * M;
+    auto KEY = [&](i64 g) -> double { return sorted_key(kp, g); };
+    auto POS = [&](i64 g) -> u32 {
+        if constexpr (sizeof(KT) == 8 && !__is_same(KT, double)) return (u32)kp[g]; else return (u32)ip[g];
+    };
 
     i64 abase, na, bbase, nb, d0;
     double med = 0.0;
@@ -525,8 +530,8 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     const i64 tot = na + nb;
     const i64 d1 = (d0 + OB < tot) ? d0 + OB : tot;
 
-    auto GA = [&](i64 i) -> double { return FOLD ? med - kp[abase - i] : kp[abase + i]; };
-    auto GB = [&](i64 j) -> double { return FOLD ? kp[bbase + j] - med : kp[bbase + j]; };
+    auto GA = [&](i64 i) -> double { return FOLD ? med - KEY(abase - i) : KEY(abase + i); };
+    auto GB = [&](i64 j) -> double { return FOLD ? KEY(bbase + j) - med : KEY(bbase + j); };
     if (tid < 64) { const i64 r0 = merge_path_wave(GA, na, GB, nb, d0); if (tid == 0) sh[0] = r0; }
     else if (tid < 128) { const i64 r1 = merge_path_wave(GA, na, GB, nb, d1); if (tid == 64) sh[1] = r1; }
     __syncthreads();
@@ -539,12 +544,12 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
         double v; u32 id;
         if (e < ca) {
             const i64 g = FOLD ? abase - (ai0 + e) : abase + ai0 + e;
-            v = FOLD ? med - kp[g] : kp[g];
-            id = ip[g];
+            v = FOLD ? med - KEY(g) : KEY(g);
+            id = POS(g);
         } else {
             const i64 g = bbase + bi0 + (e - ca);
-            v = FOLD ? kp[g] - med : kp[g];
-            id = ip[g];
+            v = FOLD ? KEY(g) - med : KEY(g);
+            id = POS(g);
         }
         skey[pos16(e)] = v;
         sidx[pos16(e)] = (IdxT)id;
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
     const i64 gfirst = sh[2 + 0] + sh[2 + 2];   // lower bounds (both runs) of the first value
     const i64 glast = sh[2 + 5] + sh[2 + 7];    // upper bounds (both runs) of the last value
     int rs[VT], re[VT];
-    block_tie_runs<NT, VT>(skey, total, reinterpret_cast<int*>(sh + 12), rs, re);
+    block_tie_runs<NT, VT>([&](int g) { return skey[pos16(g)]; }, total, reinterpret_cast<int*>(sh + 12), rs, re);
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         const int e = tid * VT + i;
@@ -642,7 +647,8 @@ __global__ __launch_bounds__(NT) void k_merge(const double* __restrict__ kin, co
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxBucketTiles = 16;
 
-__global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ keys,
+template <typename KT>      // KT = double (sorted keys) or u64 (sorted f32 records, mcr_sort32.hpp)
+__global__ __launch_bounds__(1024) void k_splitters(const KT* __restrict__ keys,
                                                     const double* __restrict__ samp, i64 M, int k, int B,
                                                     int D, i64 R, u32* __restrict__ cut, u32* __restrict__ boff)
 {
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
     u32* scut = reinterpret_cast<u32*>(splp + B + 1);    // (B+1) * k cuts
     const int tid = threadIdx.x;
     const i64 p = blockIdx.x;
-    const double* kp = keys + p * M;
+    const KT* kp = keys + p * M;
     for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; srank[i] = i % SPT; }
     for (int b = tid; b <= B; b += NTS) splt[b] = -1;      // -1 = splitter b not found (only with NaN / Inf draws)
     __syncthreads();
@@ -714,12 +720,12 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
                 int slo = 0, shi = SPT;
                 if (t < ts) { while (slo < shi) { const int m = (slo + shi) >> 1; if (!(v < sa[m])) slo = m + 1; else shi = m; } }
                 else        { while (slo < shi) { const int m = (slo + shi) >> 1; if (sa[m] < v) slo = m + 1; else shi = m; } }
-                const double* a = kp + tbase;
+                const KT* a = kp + tbase;
                 int lo = 64 * slo, hi = 64 * slo + 63;        // sample j sits at position 64 j + 63
                 if (lo > cnt) lo = cnt;
                 if (hi > cnt) hi = cnt;
-                if (t < ts) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < a[m])) lo = m + 1; else hi = m; } }
-                else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; } }
+                if (t < ts) { while (lo < hi) { const int m = (lo + hi) >> 1; if (!(v < sorted_key(a, m))) lo = m + 1; else hi = m; } }
+                else        { while (lo < hi) { const int m = (lo + hi) >> 1; if (sorted_key(a, m) < v) lo = m + 1; else hi = m; } }
                 c = (u32)lo;
             }
         }
@@ -736,7 +742,8 @@ __global__ __launch_bounds__(1024) void k_splitters(const double* __restrict__ k
 
 // Every 64th order statistic of each sorted run of length R (the regular samples of k_splitters)
 // when the runs were produced by merge passes rather than by k_tile_sort.  grid (k, P).
-__global__ __launch_bounds__(256) void k_sample_runs(const double* __restrict__ keys, i64 M, i64 R,
+template <typename KT>
+__global__ __launch_bounds__(256) void k_sample_runs(const KT* __restrict__ keys, i64 M, i64 R,
                                                      double* __restrict__ samp)
 {
     const int run = blockIdx.x, k = gridDim.x;
@@ -745,7 +752,7 @@ __global__ __launch_bounds__(256) void k_sample_runs(const double* __restrict__ 
     const i64 base = (i64)run * R;
     for (int j = threadIdx.x; j < SPT; j += 256) {
         const i64 e = base + 64 * (i64)j + 63;
-        samp[(p * k + run) * SPT + j] = (e < M && 64 * (i64)j + 63 < R) ? keys[p * M + e] : INFINITY;
+        samp[(p * k + run) * SPT + j] = (e < M && 64 * (i64)j + 63 < R) ? sorted_key(keys, p * M + e) : INFINITY;
     }
 }
 
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     __syncthreads();
     const double vfirst = skey[pos16(0)], vlast = skey[pos16(total - 1)];
     int rs[VT], re[VT];
-    block_tie_runs<NT, VT>(skey, total, sst + 24, rs, re);
+    block_tie_runs<NT, VT>([&](int g) { return skey[pos16(g)]; }, total, sst + 24, rs, re);
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         const int e = tid * VT + i;
@@ -899,24 +906,25 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
 // backends_arrow.py:40-42), statistics.median (diagnostics.py:97) and the fold split point
 // s = #(x < med).  One thread per parameter.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_order_stats(const double* __restrict__ keys, i64 M, i64 P, QArgs q,
+template <typename KT>
+__global__ void k_order_stats(const KT* __restrict__ keys, i64 M, i64 P, QArgs q,
                               double* __restrict__ res, i64* __restrict__ split)
 {
 #pragma clang fp contract(off)  // the lerp must round like numpy's (separate multiply and add)
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const double* k = keys + p * M;
+    const KT* k = keys + p * M;
     for (int j = 0; j < q.nq; ++j) {
         const i64 lo = q.lo[j], hi = (lo + 1 < M) ? lo + 1 : M - 1;
-        const double a = k[lo], b = k[hi], d = b - a, g = q.g[j];
+        const double a = sorted_key(k, lo), b = sorted_key(k, hi), d = b - a, g = q.g[j];
         res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
     }
-    const double med = (M & 1) ? k[M / 2] : (k[M / 2 - 1] + k[M / 2]) / 2.0;
+    const double med = (M & 1) ? sorted_key(k, M / 2) : (sorted_key(k, M / 2 - 1) + sorted_key(k, M / 2)) / 2.0;
     res[R_MEDIAN * P + p] = med;
     i64 lo = 0, hi = M;  // first index with k[i] >= med
     while (lo < hi) {
         const i64 mid = (lo + hi) >> 1;
-        if (k[mid] < med) lo = mid + 1; else hi = mid;
+        if (sorted_key(k, mid) < med) lo = mid + 1; else hi = mid;
     }
     split[p] = lo;
 }

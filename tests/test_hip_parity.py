@@ -348,6 +348,43 @@ def test_moments_with_an_outlying_first_draw(ctx, oracle):
         assert close(std2[p], exp["std"][p], 1e-12), (p, std2[p])
 
 
+def test_f32_records_equal_the_widened_path(ctx, oracle, monkeypatch):
+    """f32 tensors in the Arrow layout are sorted as packed (key, position) records (mcr_sort32.hpp, VERDICT r1 item
+    4).  Widening f32 -> f64 keeps order and equality, so EVERY output must be bit-identical to the f64 kernels run on
+    the same draws (MCR_F32_RECORDS=0), and equal to the oracle: one tile, many tiles, the pre-merged long path
+    (N = 100000 geometry), heavy ties, +-0, denormals, huge magnitudes."""
+    from mcmc_ref_hip import _ffi
+    monkeypatch.setenv("MCR_F32_RECORDS", "0")
+    wide = _ffi.Context(0)
+    monkeypatch.delenv("MCR_F32_RECORDS")
+    rng = np.random.default_rng(32)
+    cases = []
+    for C, N, P in ((4, 500, 3), (4, 1000, 5), (4, 10000, 4), (7, 4097, 2), (4, 16384, 2), (4, 100000, 2), (2, 131071, 1)):
+        x = (rng.normal(size=(P, C, N)) * 10.0 ** rng.integers(-3, 3, size=(P, 1, 1)) + rng.normal(size=(P, 1, 1)) * 5).astype(np.float32)
+        cases.append(x)
+    t = np.round(rng.normal(size=(3, 4, 9000)), 1).astype(np.float32)             # heavy ties
+    t[1, :, ::3] = 0.0; t[1, :, 1::3] = -0.0                                       # +-0 tie with each other
+    t[2] = (rng.integers(-3, 4, size=(4, 9000)) * 1e-42).astype(np.float32)        # denormals, few distinct values
+    cases.append(t)
+    big = (rng.normal(size=(2, 4, 5000)) * 1e30).astype(np.float32)
+    cases.append(big)
+    try:
+        for x in cases:
+            got = ctx.summarize(x, "pcn", min_chains=2)
+            ref = wide.summarize(x, "pcn", min_chains=2)
+            for k in got:
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (x.shape, k)
+            if x.shape[1] * x.shape[2] <= 70000:
+                check_summary(got, oracle.summarize(x, "pcn", min_chains=2), what=f"f32rec {x.shape}")
+        bad = cases[2].copy(); bad[1, 2, 777] = np.nan
+        for c in (ctx, wide):
+            with pytest.raises(_ffi.McrError) as e:
+                c.summarize(bad, "pcn")
+            assert e.value.code == _ffi.MCR_ENONFINITE
+    finally:
+        wide.close()
+
+
 def test_random_shapes_fuzz(ctx, oracle):
     """Seeded fuzz over shapes that cross every internal boundary: tile (4096) and bucket edges,
     1..16 tiles, segment (2048) edges, odd N, tie-heavy and constant columns, both layouts, f32."""
