@@ -2,19 +2,22 @@
 //
 // Per model (C chains x N draws, M = C*N pooled draws per parameter, P parameters) the pipeline is
 //
-//   k_ingest_*      (only if the tensor is not already f64 [P][C][N])  strided/f32 -> X[P][M] f64
-//   k_tile_sort     X -> sorted 4096-draw tiles of (key f64, idx u32) + shifted moment partials
-//                   + every 64th order statistic of each tile
+//   k_ingest_*      (only if the tensor is not in the Arrow layout [P][C][N])  strided -> X[P][M] f64
+//   k_tile_sort     X (f64, or f32 widened on load) -> sorted 4096-draw tiles of (key f64, pooled position u16 | u32)
+//                   + the tile's (count, mean, M2) + every 64th order statistic of each tile
+//                   (f32 tensors: the packed-record kernels of mcr_sort32.hpp take the first four places of this list)
 //   k_merge<false>  only for M > 64K: pairwise merge-path passes until at most 16 sorted runs remain
 //                   (k_sample_runs then takes the regular samples of those runs)
 //   k_splitters     exact k-way partition by regular sampling: deterministic bucket bound
 //   k_bucket_merge  per bucket: gather <= 16 sorted pieces, merge in LDS, write the pooled ascending
-//                   order, and (fused) tie-averaged ranks -> z = Phi^-1((r-0.5)/M) -> time order   (a7)
+//                   order, and (fused) tie-averaged ranks -> rank code -> time order                 (a7)
 //   k_order_stats   quantiles, median, fold split point                                        (a2/a3/a8)
 //   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort), fused
-//                   with ranks -> z of the folded values                                          (a8, a7)
-//   k_acov_seg / k_diag_combine (mcr_diag.hpp)  split R-hat + ESS for bulk and folded z          (a9-a13)
-//   k_finalize      mean/std from partials, rhat = pymax(bulk, tail), packs the result table
+//                   with the rank codes of the folded values                                      (a8, a7)
+//   k_acov_seg / k_diag_combine(2) / k_acov_long / k_diag_long_scan (mcr_diag.hpp)
+//                   split R-hat + ESS for bulk and folded z, lags in three tiers; combine2 also packs
+//                   mean / std / rhat = pymax(bulk, tail) into the result table (k_finalize does that
+//                   for calls without diagnostics)                                               (a9-a13)
 //   (k_rank_z: the standalone rank kernel, used only when M > 512K and no bucket partition applies)
 //
 // (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
