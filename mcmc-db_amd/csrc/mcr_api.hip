@@ -305,7 +305,7 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
             const i64 last = M - (k - 1) * R;
             const i64 sf = (k - 1) * (R / 64) + last / 64;    // finite regular samples
             w.bk_R = R; w.bk_k = (int)k;
-            w.bk_D = (int)((4096 - 79 * k) / 64);             // 64*D + 64*k + 15*k <= 4096
+            w.bk_D = (int)((4096 - 64 - 79 * k) / 64);        // 64*D + 64*k + 15*k <= 4032: the top 64 slots are the kernel's scratch
             w.bk_B = (int)((sf + w.bk_D - 1) / w.bk_D);
             if (w.bk_B < 1) w.bk_B = 1;
         }
@@ -454,7 +454,7 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
         LAUNCH(ctx, K_SPLITTERS, k_splitters<double>, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
                M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
-        LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile + 512,
+        LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile,
                (const double*)kin, (const IdxT*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
                (const u32*)a.boff, a.do_diag ? a.zb : (u32*)nullptr, pc, a.bk_R);
         std::swap(kin, kout);
@@ -468,7 +468,7 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
 template <typename IdxT, int NT, int VT>
 int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
 {
-    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT, u64>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + 256,
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT, u64>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile),
            (const u64*)kin, (const IdxT*)nullptr, (double*)nullptr, (IdxT*)nullptr, a.M, (i64)0, (const double*)a.d_res, a.pc,
            (const i64*)a.split, a.zt);
     return MCR_OK;
@@ -477,7 +477,7 @@ int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
 template <typename IdxT, int NT, int VT>
 int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
 {
-    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + 256,
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile),
            (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, (const double*)a.d_res, a.pc,
            (const i64*)a.split, a.zt);
     return MCR_OK;
@@ -579,7 +579,6 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
 {
     const i64 M = a.M, pc = a.pc;
     const unsigned py = (unsigned)pc;
-    const unsigned nblk = (unsigned)((M + kTile - 1) / kTile);
     double *kin, *kout;
     void *iin, *iout;
     bool ranked;
@@ -601,7 +600,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
                    (const double*)kin, (const u32*)iin, M, a.zb);       // no bucket path only beyond 512 K draws: u32 positions
         // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
-        const unsigned fgrid = (unsigned)((pc + 7) / 8 * 8) * nblk;
+        const unsigned fgrid = (unsigned)((pc + 7) / 8 * 8) * (unsigned)((M + (kTile - 64) - 1) / (kTile - 64));   // 4032 outputs per fold workgroup
         {
             const int rc = M <= kIdx16Max ? fold_stage_i<unsigned short>(ctx, a, kin, iin, kout, iout, fgrid)
                                           : fold_stage_i<u32>(ctx, a, kin, iin, kout, iout, fgrid);

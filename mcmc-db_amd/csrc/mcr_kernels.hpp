@@ -491,11 +491,14 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
                                               i64 R, const double* __restrict__ res, i64 P,
                                               const i64* __restrict__ split, u32* __restrict__ z)
 {
-    constexpr int OB = NT * VT;
+    constexpr int OBS = NT * VT;                            // LDS slots
+    // The fold kernel owns 64 outputs fewer than it has slots and keeps its scratch in the 64 key slots that frees:
+    // its LDS is then exactly 4096 * (8 + sizeof(IdxT)) bytes, i.e. FOUR workgroups per CU with 16-bit positions.
+    constexpr int OB = FOLD ? OBS - 64 : OBS;               // outputs per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* skey = reinterpret_cast<double*>(smem);
-    IdxT* sidx = reinterpret_cast<IdxT*>(skey + OB);
-    i64* sh = reinterpret_cast<i64*>(sidx + OB);            // 8-byte aligned: OB * sizeof(IdxT) is a multiple of 8
+    IdxT* sidx = reinterpret_cast<IdxT*>(skey + OBS);
+    i64* sh = FOLD ? reinterpret_cast<i64*>(skey + OB) : reinterpret_cast<i64*>(sidx + OBS);
 
     const int tid = threadIdx.x;
     i64 p = blockIdx.y;
@@ -643,8 +646,8 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
 // Every sorted tile contributes its 64th, 128th, ... order statistics.  In the strict total order
 // (value, tile, position) the sample of pooled sample-rank r has between 64(r+1) and 64(r+1)+64k
 // draws at or below it, so cutting at every D-th sample gives buckets of fewer than 64(D+k) draws:
-// with D = 64 - k - ceil(15k/64) a bucket, each of its <= k pieces padded to a multiple of 16,
-// always fits the 4096-slot LDS of k_bucket_merge -- a deterministic bound, no overflow path.
+// with D = floor((4032 - 79k) / 64) a bucket, each of its <= k pieces padded to a multiple of 16,
+// always fits the 4032 data slots of k_bucket_merge's LDS -- a deterministic bound, no overflow path.
 // One workgroup per parameter writes cut[p][b][t] (start of bucket b inside tile t, b = 0..B) and
 // boff[p][b] (start of bucket b in the pooled order).
 // ------------------------------------------------------------------------------------------------
@@ -780,7 +783,9 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* skey = reinterpret_cast<double*>(smem);
     IdxT* sidx = reinterpret_cast<IdxT*>(skey + T);
-    int* sst = reinterpret_cast<int*>(sidx + T);    // padded piece starts [k+1], then scratch
+    // k_splitters bounds every bucket by T - 64 slots; the 64 key slots above hold the scratch, so the workgroup's LDS
+    // is exactly T * (8 + sizeof(IdxT)) bytes: FOUR buckets per CU with 16-bit positions.
+    int* sst = reinterpret_cast<int*>(skey + (T - 64));   // padded piece starts [k+1], then scratch
     int* spl = sst + 40;                            // piece lengths [k]
     int* sps = spl + 40;                            // piece source offsets in tile [k]
     i64* sedge = reinterpret_cast<i64*>(sps + 40);  // [4] global run bounds of the edge values
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     const int padded = sst[k];          // <= 4096 by construction of D
     const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
     const i64 obase = boff[p * (B + 1) + b];
-    if (padded > T || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
+    if (padded > T - 64 || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
     // gather pieces (+inf pads)
     for (int e = tid; e < padded; e += NT) {
         int t = 0;   // last piece whose padded start is <= e (starts are non-decreasing)

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT) void k_bucket_merge32(const u64* __restrict__ r
     const int padded = sst[k];
     const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
     const i64 obase = boff[p * (B + 1) + b];
-    if (padded > T || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
+    if (padded > T - 64 || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
     for (int e = tid; e < padded; e += NT) {
         int t = 0;
 #pragma unroll

@@ -171,7 +171,7 @@ class SummaryBuffers:
     """Host arrays an mcr_summary points into (kept alive by this object)."""
 
     def __init__(self, P: int, nq: int, diagnostics: bool = True):
-        self.P, self.nq = P, nq
+        self.P, self.nq, self.diagnostics = P, nq, diagnostics
         n = max(P, 1)
         self.arrays = {k: np.full(n, np.nan) for k in SUMMARY_F64}
         self.arrays["q"] = np.full(max(P * nq, 1), np.nan)
@@ -345,9 +345,13 @@ class Context:
         return bufs.result()
 
     def enqueue(self, t: DeviceTensor, min_chains: int = 4, quantiles=(0.05, 0.5, 0.95),
-                diagnostics: bool = True) -> SummaryBuffers:
+                diagnostics: bool = True, bufs: "SummaryBuffers | None" = None) -> SummaryBuffers:
+        """Asynchronous summarize.  `bufs`: result buffers of an EARLIER, already delivered call of the same shape to
+        write into again (a caller that streams many same-shape models keeps a ring of them instead of allocating
+        twelve arrays per call)."""
         qs = self._quantiles(quantiles)
-        bufs = SummaryBuffers(t.targs[3], qs.size, diagnostics)
+        if bufs is None or bufs.P != t.targs[3] or bufs.nq != qs.size or bufs.diagnostics != diagnostics:
+            bufs = SummaryBuffers(t.targs[3], qs.size, diagnostics)
         self._check(self.lib.mcr_summarize_enqueue(self.handle, t.buf.ptr, *t.targs, int(min_chains), _as_dp(qs),
                                                    qs.size, C.byref(bufs.struct)))
         self._pending.append(bufs)
@@ -476,14 +480,15 @@ class Context:
                 for i in range(min(n.value, 32))}
 
 
-_default_ctx: Context | None = None
-_ctx_lock = threading.Lock()
+_default = threading.local()
 
 
 def default_context() -> Context:
-    """Process-wide Context on MCMC_REF_HIP_DEVICE / LOCAL_RANK / device 0."""
-    global _default_ctx
-    with _ctx_lock:
-        if _default_ctx is None:
-            _default_ctx = Context()
-        return _default_ctx
+    """The calling THREAD's Context on MCMC_REF_HIP_DEVICE / LOCAL_RANK / device 0 (created on first use).
+
+    A Context is one GPU + its streams and is not thread-safe, so the module-level convenience functions
+    (`reference.stats`, `compare.compute_basic_stats`, ...) never share one between threads: each thread gets its own."""
+    ctx = getattr(_default, "ctx", None)
+    if ctx is None or ctx.handle is None:
+        ctx = _default.ctx = Context()
+    return ctx
