@@ -25,6 +25,7 @@
 #include "mcr_kernels.hpp"
 #include "mcr_sort32.hpp"
 #include "mcr_diag.hpp"
+#include "mcr_fft.hpp"
 #include "mcr_ext.hpp"
 #include "mcr_parquet.hpp"
 #include "mcr_comm.hpp"
@@ -41,13 +42,13 @@ constexpr int kMaxGridY = 65535;
 enum KernelId {
     K_INGEST = 0, K_MOMENTS, K_MOMENTS_FINAL, K_TILE_SORT, K_MERGE, K_ORDER_STATS, K_RANK_Z, K_FOLD_MERGE,
     K_DIAG, K_FINALIZE, K_COMPARE, K_FILL, K_SPLITTERS, K_BUCKET_MERGE, K_ACOV_MORE,
-    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_ACOV_LONG, K_DIAG_LONG, K_COV_FINAL, K_COUNT
+    K_DIAG2, K_ACOV_SEG, K_TWO_SAMPLE, K_COV, K_ZTABLE, K_PQ_SNAPPY, K_PQ_DECODE, K_GATHER, K_ACOV_LONG, K_DIAG_LONG, K_COV_FINAL, K_FFT, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_ingest", "k_moments", "k_moments_final", "k_tile_sort", "k_merge", "k_order_stats", "k_rank_z",
     "k_fold_merge", "k_diag", "k_finalize", "k_compare", "k_fill_synth", "k_splitters",
     "k_bucket_merge", "k_acov_more", "k_diag_combine2", "k_acov_seg", "k_two_sample", "k_cov_mfma", "k_ztable",
-    "k_pq_snappy", "k_pq_decode", "k_gather_rows", "k_acov_long", "k_diag_long_scan", "k_cov_final"};
+    "k_pq_snappy", "k_pq_decode", "k_gather_rows", "k_acov_long", "k_diag_long_scan", "k_cov_final", "k_fft"};
 
 struct EvPair { hipEvent_t a, b; int kid; };
 
@@ -100,6 +101,8 @@ struct mcr_ctx {
     // the context instead of being relaunched by every call (most recently used first; a handful of shapes is typical)
     struct ZTab { i64 M; double* tab; };
     std::vector<ZTab> ztabs;
+    struct Twiddle { int L; double2* tab; };          // exp(-2 pi i t / L), t < L / 2, per sub-transform length (mcr_fft.hpp)
+    std::vector<Twiddle> twiddles;
     Slot slots[MCR_MAX_INFLIGHT];
     int n_inflight = 0, next_slot = 0;
     std::vector<int> order;  // busy slots in enqueue order
@@ -111,6 +114,7 @@ struct mcr_ctx {
     // hipGraph cache: the launch sequence of one summarize call is static for a given shape,
     // buffer set and slot, so it is captured once and replayed (removes ~5 us of host launch gap
     // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
+    bool fft_on = true;      // MCR_FFT=0: long chains take the direct tier-3 rounds only (A/B measurements, parity tests)
     bool f32_records = true; // MCR_F32_RECORDS=0: f32 tensors take the f64 kernels (widened by the tile sort) instead of mcr_sort32.hpp
     int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
     bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
@@ -246,6 +250,43 @@ int get_ztab(mcr_ctx* ctx, i64 M, double** out)
     return MCR_OK;
 }
 
+// Twiddle table of a sub-transform length (at most 11 distinct lengths exist), from the context's cache.
+int get_twiddles(mcr_ctx* ctx, int L, double2** out)
+{
+    for (const mcr_ctx::Twiddle& t : ctx->twiddles)
+        if (t.L == L) { *out = t.tab; return MCR_OK; }
+    double2* tab = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&tab, sizeof(double2) * (size_t)(L / 2 > 1 ? L / 2 : 1)));
+    hipLaunchKernelGGL(fft::k_fft_twiddles, dim3((unsigned)((L / 2 + 255) / 256)), dim3(256), 0, ctx->stream, tab, L);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(tab); return fail(ctx, MCR_EHIP, "k_fft_twiddles failed: %s", hipGetErrorString(e)); }
+    ctx->twiddles.push_back(mcr_ctx::Twiddle{L, tab});
+    *out = tab;
+    return MCR_OK;
+}
+
+// FFT tier of the ESS lags: chains of more than kFftMinN draws (and at most 2^21, so that N = 2^ceil(log2 2n) splits
+// into two sub-transforms of at most 2048).  slots = listed pairs served per call (the rest take the direct rounds).
+constexpr i64 kFftMinN = 16384;
+constexpr int kFftChainBatch = 4;
+struct FftPlan { bool on = false; int logN = 0, log1 = 0, log2 = 0, slots = 0, cb = 0; size_t bytes = 0; };
+FftPlan plan_fft(i64 n, int C, bool enabled)
+{
+    FftPlan f;
+    if (!enabled || n <= kFftMinN || C < 2) return f;
+    int lg = 1;
+    while (((i64)1 << lg) < 2 * n) ++lg;
+    if (lg > 22) return f;
+    f.on = true; f.logN = lg; f.log1 = lg / 2; f.log2 = lg - f.log1;
+    const i64 N = (i64)1 << lg;
+    i64 slots = ((i64)1 << 23) / N;
+    f.slots = (int)(slots < 2 ? 2 : (slots > 32 ? 32 : slots));
+    f.cb = C < kFftChainBatch ? C : kFftChainBatch;
+    f.bytes = (size_t)f.slots * ((size_t)f.cb * N * 16 + (size_t)N * 8 + (size_t)N * 16) + 3 * 256;
+    return f;
+}
+
 int ensure_slot(mcr_ctx* ctx, Slot& s, size_t res_doubles, size_t off_entries)
 {
     if (res_doubles > s.res_cap || off_entries > s.off_cap) {
@@ -343,6 +384,9 @@ struct PipeIn {
     double* acov;        // [pc][2][n] deviation products of tier 3 (lags >= 256), listed pairs only
     unsigned* long_count; // [1] number of pairs in the tier-3 list of this call
     unsigned* long_list;  // [2 pc]
+    FftPlan fft;          // FFT tier for long chains (mcr_fft.hpp): buffers shared by the chunks of a call
+    double2 *fft_A = nullptr, *fft_B = nullptr; double* fft_S = nullptr;
+    double2 *tw1 = nullptr, *tw2 = nullptr;
     i64 nstage;          // longest chain prefix the segment grid has to cover
     double* ztab;        // [2M] z of every possible tie run (shared by all parameters of the call)
     double* samp;        // [pc][ntiles][64] regular samples of the sorted tiles
@@ -390,16 +434,40 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
            (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB, a.long_count, a.long_list,   // kA / kB: the sort's key buffers, free by now
            (const double*)a.part, (int)a.ntiles);
-    // tier 3 for the pairs still undecided at lag 256: rounds [256, 16384), [16384, 262144), ... over the whole chip
-    // (chains of up to 16384 draws: ONE round, i.e. two near-empty launches when no pair is listed)
+    // tier 3 for the pairs still undecided at lag 256.
+    //  * chains of more than 16 384 draws: ALL lags of the first fft.slots listed pairs by FFT (mcr_fft.hpp);
+    //  * everything else (and list entries beyond those slots): direct products over the whole chip, in rounds
+    //    [256, 16384) -- one round, i.e. two near-empty launches, for chains up to 16 384 draws -- then growing 4x.
+    unsigned slot_from = 0;
+    if (a.fft.on) {
+        const fft::Plan pl{a.fft.log1, a.fft.log2};
+        const int N1 = 1 << pl.log1, N2 = 1 << pl.log2, cols = fft::kColElems >> pl.log1;
+        const unsigned F = (unsigned)a.fft.slots;
+        const size_t lds_cols = (size_t)fft::kColElems * 16, lds_rows = (size_t)N2 * 16;
+        for (int c0 = 0; c0 < a.C; c0 += a.fft.cb) {
+            const int nb = (a.C - c0 < a.fft.cb) ? a.C - c0 : a.fft.cb;
+            LAUNCH(ctx, K_FFT, (fft::k_fft_cols<256>), dim3((unsigned)(N2 / cols), (unsigned)nb, F), dim3(256), lds_cols,
+                   (const double*)a.kA, (const double*)a.kB, a.M, a.d_off, c0, a.n, pl, (const double2*)a.tw1,
+                   (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state, a.fft_A, a.fft.cb);
+            LAUNCH(ctx, K_FFT, (fft::k_fft_rows_power<256>), dim3((unsigned)N1, F), dim3(256), lds_rows, (const double2*)a.fft_A, pl,
+                   (const double2*)a.tw2, (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state,
+                   a.fft_S, a.fft.cb, nb, c0 == 0 ? 1 : 0);
+        }
+        LAUNCH(ctx, K_FFT, (fft::k_fft_rows_spec<256>), dim3((unsigned)N1, F), dim3(256), lds_rows, (const double*)a.fft_S, pl,
+               (const double2*)a.tw2, (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state, a.fft_B);
+        LAUNCH(ctx, K_FFT, (fft::k_fft_cols_out<256>), dim3((unsigned)(N2 / cols), F), dim3(256), lds_cols, (const double2*)a.fft_B, pl,
+               (const double2*)a.tw1, a.n, (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state,
+               a.acov);
+        slot_from = F;
+    }
     const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
     for (i64 L0 = kLag2; L0 < a.n;) {
-        const i64 L1 = (L0 < 16384) ? 16384 : L0 * 16;
+        const i64 L1 = (L0 < 16384) ? 16384 : L0 * 4;
         const i64 lend = (L1 < a.n) ? L1 : a.n;
         const unsigned groups = (unsigned)((lend - L0 + kLongGroup - 1) / kLongGroup);
         LAUNCH(ctx, K_ACOV_LONG, (k_acov_long<256>), dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB,
                a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
-               (const double*)a.state, a.acov);
+               (const double*)a.state, a.acov, slot_from);
         LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
                (const unsigned*)a.long_list, a.state, (const double*)a.acov, a.d_res, a.pc);
         L0 = L1;
@@ -731,7 +799,24 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
         // as it loads); anything else goes through one ingest pass into X[P][M] f64
         const bool ingest = !((N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
         const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
-        const size_t slack = 40 * 256;
+        const bool do_diag_early = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
+                                   out->lag_bulk || out->lag_tail;
+        FftPlan fp = plan_fft(N, (int)C, do_diag_early && ctx->fft_on);
+        // the FFT tier is an accelerator, not a requirement: under a tight workspace limit it gets fewer slots, or none
+        // (the direct rounds then serve every listed pair), but at least a third of the limit stays with the parameters
+        while (fp.on && fp.bytes > ctx->ws_limit / 3) {
+            if (fp.slots <= 1) { fp = FftPlan{}; break; }
+            fp.slots /= 2;
+            const size_t Nf = (size_t)1 << fp.logN;
+            fp.bytes = (size_t)fp.slots * ((size_t)fp.cb * Nf * 16 + Nf * 8 + Nf * 16) + 3 * 256;
+        }
+        double2 *tw1 = nullptr, *tw2 = nullptr;
+        if (fp.on) {
+            rc = get_twiddles(ctx, 1 << fp.log1, &tw1);
+            if (!rc) rc = get_twiddles(ctx, 1 << fp.log2, &tw2);
+            if (rc) return rc;
+        }
+        const size_t slack = 40 * 256 + fp.bytes;
         if (wp.per_param + slack > ctx->ws_limit)
             return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
@@ -781,6 +866,13 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
                 a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
                 a.do_diag = do_diag;
+                a.fft = fp; a.tw1 = tw1; a.tw2 = tw2;
+                if (fp.on) {
+                    const size_t Nf = (size_t)1 << fp.logN;
+                    a.fft_A = cv.take<double2>((size_t)fp.slots * fp.cb * Nf);
+                    a.fft_S = cv.take<double>((size_t)fp.slots * Nf);
+                    a.fft_B = cv.take<double2>((size_t)fp.slots * Nf);
+                }
                 if (ingest) {
                     double* X = cv.take<double>((size_t)pc * M);
                     const int r2 = (dtype == MCR_F64) ? launch_ingest<double>(ctx, draws_dev, X, C, N, pc, sc, sn, sp, p0)
@@ -975,6 +1067,7 @@ int mcr_init(int device, mcr_ctx** out)
     ctx->ws_limit = mb << 20;
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
+    if (const char* env = getenv("MCR_FFT")) ctx->fft_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_SORT_CFG")) {
         const int v = atoi(env);
         if (v >= 0 && v % 10 <= 1 && v / 10 <= 2) ctx->sort_cfg = v;
@@ -1002,6 +1095,7 @@ void mcr_free(mcr_ctx* ctx)
     ctx->lane_ws[0] = ctx->ws;
     for (void* w : ctx->lane_ws) if (w) hipFree(w);
     for (const mcr_ctx::ZTab& z : ctx->ztabs) hipFree(z.tab);
+    for (const mcr_ctx::Twiddle& t : ctx->twiddles) hipFree(t.tab);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->pq_stage) hipFree(ctx->pq_stage);
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
@@ -1196,7 +1290,11 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         if (len >= 2 && len / 2 + nh > nstage) nstage = len / 2 + nh;
     }
     const WsPlan wp = plan_ws(M, C, true, want_dbg, nstage);
-    const size_t slack = 40 * 256;
+    FftPlan fp = plan_fft(n, C, ctx->fft_on);
+    fp.slots = fp.on ? 2 : 0;                       // one parameter: two (parameter, kind) pairs at most
+    if (fp.on) { const size_t Nf = (size_t)1 << fp.logN; fp.bytes = (size_t)fp.slots * ((size_t)fp.cb * Nf * 16 + Nf * 8 + Nf * 16) + 3 * 256; }
+    if (fp.on && wp.per_param + 40 * 256 + fp.bytes > ctx->ws_limit) fp = FftPlan{};
+    const size_t slack = 40 * 256 + fp.bytes;
     if (wp.per_param + slack > ctx->ws_limit) return fail(ctx, MCR_ENOMEM, "workspace limit too small for %lld draws", M);
     int rc = ensure_ws(ctx, wp.per_param + slack);
     if (rc) return rc;
@@ -1232,6 +1330,16 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.cut = cv.take<u32>((size_t)(wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)(wp.bk_B + 1));
     a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
+    a.fft = fp;
+    if (fp.on) {
+        rc = get_twiddles(ctx, 1 << fp.log1, &a.tw1);
+        if (!rc) rc = get_twiddles(ctx, 1 << fp.log2, &a.tw2);
+        if (rc) return rc;
+        const size_t Nf = (size_t)1 << fp.logN;
+        a.fft_A = cv.take<double2>((size_t)fp.slots * fp.cb * Nf);
+        a.fft_S = cv.take<double>((size_t)fp.slots * Nf);
+        a.fft_B = cv.take<double2>((size_t)fp.slots * Nf);
+    }
     double* X = cv.take<double>((size_t)M);
     double* dbg[4] = {nullptr, nullptr, nullptr, nullptr};     // z_bulk, z_tail, rank_bulk, rank_tail (decoded codes)
     if (want_dbg) for (int i = 0; i < 4; ++i) dbg[i] = cv.take<double>((size_t)M);

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
                                                   i64 M, const i64* __restrict__ off, int C, i64 n, i64 L0, i64 L1,
                                                   const unsigned* __restrict__ long_count,
                                                   const unsigned* __restrict__ long_list,
-                                                  const double* __restrict__ state, double* __restrict__ acov)
+                                                  const double* __restrict__ state, double* __restrict__ acov,
+                                                  unsigned slot_from)
 {
     constexpr int NW = NT / kWave, SEG = kSeg;
     constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + kLongGroup + 16) / 8 * 10;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
     const i64 lend = (L1 < n) ? L1 : n;
     const i64 lbase = L0 + (i64)kLongGroup * blockIdx.x;
     if (lbase >= lend) return;
-    for (unsigned slot = blockIdx.y; slot < count; slot += gridDim.y) {
+    for (unsigned slot = slot_from + blockIdx.y; slot < count; slot += gridDim.y) {     // entries below slot_from: served by the FFT tier
         const i64 pk = long_list[slot];
         if (state[pk * kPairState + 3] != 0.0) continue;            // decided in an earlier round
         const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;

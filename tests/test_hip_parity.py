@@ -311,6 +311,49 @@ def test_long_lag_tier3_random_walks(ctx, oracle):
         assert close(g[k], e[k], TIGHT), (k, g[k], e[k])
 
 
+def test_long_chains_fft_tier_equals_direct_tier_and_oracle(ctx, oracle, monkeypatch):
+    """Chains of more than 16 384 draws take their long lags from the FFT tier (mcr_fft.hpp: zero-padded four-step
+    FFT, |.|^2 summed over chains, second FFT); MCR_FFT=0 keeps them on the direct products.  Both must give the
+    oracle's integer truncation lags exactly and its ESS to 1e-9: random walks (lags in the thousands and tens of
+    thousands), more listed pairs than the FFT has slots (the rest fall through to the direct rounds), N not a power
+    of two, two chains, ragged chains."""
+    import time
+    from mcmc_ref_hip import _ffi
+    monkeypatch.setenv("MCR_FFT", "0")
+    direct = _ffi.Context(0)
+    monkeypatch.delenv("MCR_FFT")
+    rng = np.random.default_rng(8)
+    try:
+        x = np.cumsum(rng.normal(size=(18, 4, 17001)), axis=2) * 0.01           # 36 listed pairs > 32 FFT slots (N = 2^16)
+        x[5] = rng.normal(size=(4, 17001))
+        exp = oracle.summarize(x, "pcn")
+        assert int(min(exp["lag_bulk"][0], exp["lag_tail"][0])) > 256
+        for c, name in ((ctx, "fft"), (direct, "direct")):
+            check_summary(c.summarize(x, "pcn"), exp, what=f"long-{name}")
+        y = np.cumsum(rng.normal(size=(1, 2, 60000)), axis=2) * 0.01             # N = 2^17, two chains
+        expy = oracle.summarize(y, "pcn", min_chains=2)
+        t = ctx.upload(y, "pcn"); td = direct.upload(y, "pcn")
+        try:
+            for c, tt, name in ((ctx, t, "fft"), (direct, td, "direct")):
+                c.summarize(tt, min_chains=2)
+                t0 = time.perf_counter()
+                got = c.summarize(tt, min_chains=2)
+                ms = (time.perf_counter() - t0) * 1e3
+                check_summary(got, expy, what=f"long2-{name}")
+                print(f"\nrandom walk 2 x 60000, lags {int(got['lag_bulk'][0])} / {int(got['lag_tail'][0])}, {name}: {ms:.2f} ms per call")
+        finally:
+            t.free(); td.free()
+        chains = [list(np.cumsum(rng.normal(size=n)) * 0.01) for n in (21000, 17500, 30000)]     # ragged: n = 17500
+        e = oracle.diag(chains, 2)
+        for c in (ctx, direct):
+            g = c.diagnose_chains(chains, 2)
+            assert (g["lag_bulk"], g["lag_tail"]) == (e["lag_bulk"], e["lag_tail"])
+            for k in ("rhat", "ess_bulk", "ess_tail"):
+                assert close(g[k], e[k], TIGHT), (k, g[k], e[k])
+    finally:
+        direct.close()
+
+
 def test_moments_with_an_outlying_first_draw(ctx, oracle):
     """the moments used to be shifted by the parameter's FIRST draw in a single pass, so an unconverged
     start (first draw d sigma away) cost d^2 eps of accuracy in std.  Now every tile / slice is two-pass around its
