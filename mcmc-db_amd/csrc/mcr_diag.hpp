@@ -30,10 +30,15 @@
 #pragma once
 #include "mcr_device.hpp"
 
+#ifndef MCR_ACOV_LPL
+#define MCR_ACOV_LPL 8
+#endif
+
 namespace mcr {
 
 constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (1024 for chains of <= 1024 draws)
 constexpr int kLag1 = 64;       // tier 1: lags 0 .. 63 (a multiple of 8, at most 64: one lag per lane in k_diag_combine)
+constexpr int kLpl1 = MCR_ACOV_LPL;  // lags per lane of tier 1's register tile (8 x 8 or 8 x 16)
 constexpr int kSegRec = kLag1 + 8;   // doubles per tier-1 record: the lag products + 7 scalars
 constexpr int kMoreBlocks = 3;  // tier 2: lags 64 .. 64 + 64*3 - 1 = 255
 constexpr int kLag2 = kLag1 + 64 * kMoreBlocks;   // first lag of tier 3
@@ -71,56 +76,60 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
     __syncthreads();
 }
 
-// One block of 8 * LG lags of raw products for a staged segment, accumulated into the lane's 8 registers.
+// One block of LPL * LG lags of raw products for a staged segment, accumulated into the lane's LPL registers.
 // A: swizzled segment (>= seglen rounded up to 8 * 64 / LG draws), B: swizzled window that starts `lag base`
-// draws later (8 * LG + 16 draws longer); both zero padded.  Lane (g, ph) = (lane % LG, lane / LG) owns lags
-// 8g .. 8g+7 of the block and draws 8 ph .. 8 ph + 7 of every span of 8 * 64 / LG draws; the waves split the spans.
-template <int NT, int LG>
+// draws later (LPL * LG + 16 draws longer); both zero padded.  Lane (g, ph) = (lane % LG, lane / LG) owns lags
+// LPL g .. LPL g + LPL - 1 of the block and draws 8 ph .. 8 ph + 7 of every span of 8 * 64 / LG draws; the waves split
+// the spans.  LPL = 8: 12 ds_read_b128 per 64 FMAs; LPL = 16: 16 per 128 (the loop is LDS-bandwidth-bound: four waves
+// of a CU share one LDS, 8 cycles per b128 read, against 4 cycles per fp64 FMA on each of the four SIMDs).
+template <int NT, int LG, int LPL = 8>
 __device__ __forceinline__ void seg_accumulate(const double* __restrict__ A, const double* __restrict__ B,
-                                               int seglen, double (&acc)[8])
+                                               int seglen, double (&acc)[LPL])
 {
+    static_assert(LPL == 8 || LPL == 16, "8 or 16 lags per lane");
     constexpr int NW = NT / kWave, PH = 64 / LG, SPAN = PH * 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane % LG, ph = lane / LG;
     const int nit = (seglen + SPAN - 1) / SPAN;
     for (int it = w; it < nit; it += NW) {
         const int i0 = it * SPAN + (ph << 3);
-        const int s = i0 + (g << 3);
+        const int s = i0 + g * LPL;
         const double2* pa = reinterpret_cast<const double2*>(A + 10 * (i0 >> 3));
         const double2* pb = reinterpret_cast<const double2*>(B + 10 * (s >> 3));
-        double a[8], b[16];
+        double a[8], b[LPL + 8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const double2 v = pa[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const double2 v = pb[j]; b[2 * j] = v.x; b[2 * j + 1] = v.y; }
+        for (int q = 0; q < (LPL + 8) / 8; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const double2 v = pb[5 + j]; b[8 + 2 * j] = v.x; b[9 + 2 * j] = v.y; }
+            for (int j = 0; j < 4; ++j) { const double2 v = pb[5 * q + j]; b[8 * q + 2 * j] = v.x; b[8 * q + 2 * j + 1] = v.y; }
 #pragma unroll
-        for (int li = 0; li < 8; ++li)
+        for (int li = 0; li < LPL; ++li)
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[li] = fma(a[k], b[k + li], acc[li]);
     }
 }
 
-// Sums the lanes' registers of one lag block over phases and waves: tot[0 .. 8 * LG).  All NT threads must call it.
-template <int NT, int LG>
-__device__ __forceinline__ void seg_reduce(double (&acc)[8], double* tot, double* wred)
+// Sums the lanes' registers of one lag block over phases and waves: tot[0 .. LPL * LG).  All NT threads must call it.
+template <int NT, int LG, int LPL = 8>
+__device__ __forceinline__ void seg_reduce(double (&acc)[LPL], double* tot, double* wred)
 {
     constexpr int NW = NT / kWave;
+    static_assert(LPL * LG <= 64, "a block is at most 64 lags");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane % LG, ph = lane / LG;
 #pragma unroll
-    for (int li = 0; li < 8; ++li) {
+    for (int li = 0; li < LPL; ++li) {
 #pragma unroll
         for (int o = LG; o < 64; o <<= 1) acc[li] += __shfl_xor(acc[li], o, kWave);
     }
     __syncthreads();  // wred / tot may still be in use
     if (ph == 0) {
 #pragma unroll
-        for (int li = 0; li < 8; ++li) wred[w * 64 + (g << 3) + li] = acc[li];
+        for (int li = 0; li < LPL; ++li) wred[w * 64 + g * LPL + li] = acc[li];
     }
     __syncthreads();
-    if (tid < 8 * LG) {
+    if (tid < LPL * LG) {
         double t = 0.0;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) t += wred[ww * 64 + tid];
@@ -129,15 +138,15 @@ __device__ __forceinline__ void seg_reduce(double (&acc)[8], double* tot, double
     __syncthreads();
 }
 
-template <int NT, int LG>
+template <int NT, int LG, int LPL = 8>
 __device__ __forceinline__ void seg_products(const double* __restrict__ A, const double* __restrict__ B,
                                              int seglen, double* tot, double* wred)
 {
-    double acc[8];
+    double acc[LPL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-    seg_accumulate<NT, LG>(A, B, seglen, acc);
-    seg_reduce<NT, LG>(acc, tot, wred);
+    for (int i = 0; i < LPL; ++i) acc[i] = 0.0;
+    seg_accumulate<NT, LG, LPL>(A, B, seglen, acc);
+    seg_reduce<NT, LG, LPL>(acc, tot, wred);
 }
 
 // FIRST == true : lags 0..kLag1-1 + the segment's sums (record of kSegRec doubles), every pair.
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
                                                  const unsigned* __restrict__ more, double* __restrict__ rec)
 {
     constexpr int NW = NT / kWave;
-    static_assert(SEG % 128 == 0, "spans of the 32-lag tile are 128 draws");
+    static_assert(SEG % 128 == 0, "spans of the widest tile are 128 draws");
     constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + 80) / 8 * 10;
     __shared__ __attribute__((aligned(16))) double sB[LB];
     __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
             r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
             r[SG_MIN] = vmin; r[SG_MAX] = vmax;
         }
-        seg_products<NT, kLag1 / 8>(sB, sB, seglen, tot, wred);
+        seg_products<NT, kLag1 / kLpl1, kLpl1>(sB, sB, seglen, tot, wred);
         if (tid < kLag1) r[tid] = tot[tid];
     } else {
         if (seglen == 0) {   // nothing of [0, n) in this segment: zero record
