@@ -7,7 +7,7 @@
 // chain to N >= 2n (no circular wrap), |FFT|^2 summed over the chains, one more FFT of that real, even spectrum, and
 // acov[lag] = Re(result)[lag] / N.  The scan for the first negative rho (k_diag_long_scan) is the same as for the
 // direct tiers; the integer truncation lag is exact as long as no rho lies within the FFT's round-off (~1e-14 of
-// rho_0) of zero, which the parity tests check on random walks against the oracle.
+// rho_0) of zero, which the parity tests check on random walks against the CPU restatement of the reference.
 //
 // Layout (four-step, N = N1 x N2, both powers of two <= 2048, every sub-transform in LDS):
 //   FFT 1 (natural in, transposed out):  X[k1 + N1 k2] = sum_n2 W_N^(n2 k1) [sum_n1 x[n1 N2 + n2] W_N1^(n1 k1)] W_N2^(n2 k2)

@@ -812,16 +812,41 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
     const i64 obase = boff[p * (B + 1) + b];
     if (padded > T - 64 || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
-    // gather pieces (+inf pads)
-    for (int e = tid; e < padded; e += NT) {
-        int t = 0;   // last piece whose padded start is <= e (starts are non-decreasing)
+    // gather pieces (+inf pads).  Slot e = j * NT + tid: a wave's j-th load covers 64 consecutive slots = four 16-slot
+    // chunks, and a chunk never straddles pieces (they are padded to 16).  Lane l < 4 VT looks up the piece of chunk
+    // (l / 4, l % 4) ONCE; the element loop fetches {source offset, live length} from that lane and issues all VT
+    // loads back to back (one piece search per 16 slots instead of one per slot, no load waits for the previous one).
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        u32 my_g = 0; int my_n = 0;
+        if (lane < 4 * VT) {
+            const int e0 = (lane >> 2) * NT + 64 * wv + 16 * (lane & 3);
+            if (e0 < padded) {
+                int t = 0;   // last piece whose padded start is <= e0 (starts are non-decreasing)
 #pragma unroll
-        for (int step = 8; step > 0; step >>= 1)
-            if (t + step < k && e >= sst[t + step]) t += step;
-        const int o = e - sst[t];
-        double v = INFINITY; IdxT id = (IdxT)~(IdxT)0;
-        if (o < spl[t]) { const i64 g = (i64)t * R + sps[t] + o; v = kp[g]; id = ip[g]; }
-        skey[pos16(e)] = v; sidx[pos16(e)] = id;
+                for (int step = 8; step > 0; step >>= 1)
+                    if (t + step < k && e0 >= sst[t + step]) t += step;
+                const int o = e0 - sst[t];
+                my_n = spl[t] - o;
+                my_g = (u32)((i64)t * R) + (u32)sps[t] + (u32)o;
+            }
+        }
+        double gv[VT]; IdxT gi[VT];
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int from = 4 * j + (lane >> 4), within = lane & 15;
+            const u32 g0 = (u32)__shfl((int)my_g, from);
+            const int n = __shfl(my_n, from);
+            const bool live = within < n;
+            const i64 g = live ? (i64)(g0 + (u32)within) : 0;     // dead slots read element 0 (always there) and drop it
+            const double v = kp[g]; const IdxT id = ip[g];
+            gv[j] = live ? v : INFINITY; gi[j] = live ? id : (IdxT)~(IdxT)0;
+        }
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            if (e < padded) { skey[pos16(e)] = gv[j]; sidx[pos16(e)] = gi[j]; }
+        }
     }
     __syncthreads();
     // merge rounds over adjacent runs (run boundaries = sst[] at stride 2^r)

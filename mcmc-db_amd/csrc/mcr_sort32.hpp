@@ -224,13 +224,36 @@ __global__ __launch_bounds__(NT) void k_bucket_merge32(const u64* __restrict__ r
     const int total = (int)(boff[p * (B + 1) + b + 1] - boff[p * (B + 1) + b]);
     const i64 obase = boff[p * (B + 1) + b];
     if (padded > T - 64 || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
-    for (int e = tid; e < padded; e += NT) {
-        int t = 0;
+    {   // gather: one piece search per 16-slot chunk, all VT loads in flight together (see k_bucket_merge)
+        const int lane = tid & 63, wv = tid >> 6;
+        u32 my_g = 0; int my_n = 0;
+        if (lane < 4 * VT) {
+            const int e0 = (lane >> 2) * NT + 64 * wv + 16 * (lane & 3);
+            if (e0 < padded) {
+                int t = 0;
 #pragma unroll
-        for (int step = 8; step > 0; step >>= 1)
-            if (t + step < k && e >= sst[t + step]) t += step;
-        const int o = e - sst[t];
-        srec[pos16(e)] = (o < spl[t]) ? rp[(i64)t * R + sps[t] + o] : kRecPad;
+                for (int step = 8; step > 0; step >>= 1)
+                    if (t + step < k && e0 >= sst[t + step]) t += step;
+                const int o = e0 - sst[t];
+                my_n = spl[t] - o;
+                my_g = (u32)((i64)t * R) + (u32)sps[t] + (u32)o;
+            }
+        }
+        u64 gr[VT];
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int from = 4 * j + (lane >> 4), within = lane & 15;
+            const u32 g0 = (u32)__shfl((int)my_g, from);
+            const int n = __shfl(my_n, from);
+            const bool live = within < n;
+            const u64 r = rp[live ? (i64)(g0 + (u32)within) : 0];
+            gr[j] = live ? r : kRecPad;
+        }
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            if (e < padded) srec[pos16(e)] = gr[j];
+        }
     }
     __syncthreads();
     const int chunk0 = tid * VT;
