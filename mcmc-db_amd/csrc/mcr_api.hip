@@ -353,7 +353,7 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
     }
     w.per_param = (size_t)(w.ntiles + 16) * 64 * 8 + (size_t)(w.bk_B + 1) * ((size_t)w.bk_k + 1) * 4 + 16 +
                   (size_t)M * (8 + 4) * 2 + (size_t)M * 4 * 2 + (ingest ? (size_t)M * 8 : 0) +
-                  (ranks ? (size_t)M * 32 + 1024 : 0) + (size_t)w.ntiles * 32 + 8 +
+                  (ranks ? (size_t)M * 32 + 1024 : 0) + (size_t)w.ntiles * kMomRec * 8 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) *
                       ((size_t)((nstage + kSeg - 1) / kSeg + 1) * (kSegRec + 64 * kMoreBlocks) + kChState) * 8 +
                   (size_t)2 * (size_t)(nstage > 0 ? nstage : 1) * 8 + 2 * 4 + 2 * kPairState * 8 +
@@ -846,7 +846,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.kA = cv.take<double>((size_t)pc * M); a.kB = cv.take<double>((size_t)pc * M);
                 a.iA = cv.take<u32>((size_t)pc * M);    a.iB = cv.take<u32>((size_t)pc * M);
                 a.zb = cv.take<u32>((size_t)pc * M); a.zt = cv.take<u32>((size_t)pc * M);
-                a.part = cv.take<double>((size_t)pc * wp.ntiles * 4);
+                a.part = cv.take<double>((size_t)pc * wp.ntiles * kMomRec);
                 a.split = cv.take<i64>((size_t)pc);
                 {
                     const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((N + kSeg - 1) / kSeg + 1);
@@ -1310,7 +1310,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
     a.kA = cv.take<double>((size_t)M); a.kB = cv.take<double>((size_t)M);
     a.iA = cv.take<u32>((size_t)M);    a.iB = cv.take<u32>((size_t)M);
     a.zb = cv.take<u32>((size_t)M); a.zt = cv.take<u32>((size_t)M);
-    a.part = cv.take<double>((size_t)wp.ntiles * 4);
+    a.part = cv.take<double>((size_t)wp.ntiles * kMomRec);
     a.split = cv.take<i64>(1);
     {
         const size_t cc = (size_t)(C > 0 ? C : 1), ns = (size_t)((nstage + kSeg - 1) / kSeg + 1);
@@ -1396,11 +1396,11 @@ int mcr_moments_dev(mcr_ctx* ctx, const void* draws_dev, int dtype, int64_t C, i
         if (S < 1) S = 1;
         if (S > kMaxGridY) S = kMaxGridY;
     }
-    const size_t need = align_up((size_t)P * S * 32, 256) + align_up((size_t)P * 8, 256) * 2 + 1024;
+    const size_t need = align_up((size_t)P * S * kMomRec * 8, 256) + align_up((size_t)P * 8, 256) * 2 + 1024;
     int rc = ensure_ws(ctx, need);
     if (rc) return rc;
     Carve cv{reinterpret_cast<char*>(ctx->ws)};
-    double* part = cv.take<double>((size_t)P * S * 4);
+    double* part = cv.take<double>((size_t)P * S * kMomRec);
     double* d_mean = cv.take<double>((size_t)P);
     double* d_std = cv.take<double>((size_t)P);
     rc = dtype == MCR_F64 ? moments_impl<double>(ctx, (const double*)draws_dev, C, N, P, sc, sn, sp, d_mean, d_std, part, S, rows)
@@ -1462,7 +1462,7 @@ static int carve_sort(mcr_ctx* ctx, Carve& cv, i64 M, i64 P, PipeIn& a)
     a.M = M; a.pc = P; a.C = 1; a.ntiles = wp.ntiles; a.do_diag = false;
     a.kA = cv.take<double>((size_t)P * M); a.kB = cv.take<double>((size_t)P * M);
     a.iA = cv.take<u32>((size_t)P * M);    a.iB = cv.take<u32>((size_t)P * M);
-    a.part = cv.take<double>((size_t)P * wp.ntiles * 4);
+    a.part = cv.take<double>((size_t)P * wp.ntiles * kMomRec);
     a.samp = cv.take<double>((size_t)P * (wp.ntiles + 16) * 64);
     a.cut = cv.take<u32>((size_t)P * (wp.bk_B + 1) * (size_t)(wp.bk_k + 1));
     a.boff = cv.take<u32>((size_t)P * (wp.bk_B + 1));
@@ -1558,12 +1558,12 @@ int mcr_covariance_dev(mcr_ctx* ctx, const double* draws_dev, int64_t M, int64_t
     kchunk = (kchunk + kCovBK - 1) / kCovBK * kCovBK;
     ksplit = (int)((M + kchunk - 1) / kchunk);
     const int S = 8;
-    const size_t need = (size_t)ksplit * P64 * P64 * 8 + (size_t)P * (S * 32 + 16) + 16 * 256;
+    const size_t need = (size_t)ksplit * P64 * P64 * 8 + (size_t)P * (S * kMomRec * 8 + 16) + 16 * 256;
     int rc = ensure_ws(ctx, need);
     if (rc) return rc;
     Carve cv{reinterpret_cast<char*>(ctx->ws)};
     double* partial = cv.take<double>((size_t)ksplit * P64 * P64);
-    double* mpart = cv.take<double>((size_t)P * S * 4);
+    double* mpart = cv.take<double>((size_t)P * S * kMomRec);
     double* d_mean = cv.take<double>((size_t)P);
     double* d_std = cv.take<double>((size_t)P);
     rc = moments_impl<double>(ctx, draws_dev, 1, M, P, M, 1, M, d_mean, d_std, mpart, (M >= 8 * 2048) ? S : 1, true);

@@ -15,11 +15,47 @@ using u64 = unsigned long long;
 constexpr int kWave = 64;
 
 // ---- reductions ----------------------------------------------------------------------------
+// Cross-lane traffic goes through DPP (a VALU operand modifier: no LDS crossbar, no waitcnt) wherever the pattern is
+// one DPP can express; __shfl_xor compiles to two ds_bpermute_b32 per double and step, which made the seven
+// reductions of k_acov_seg's staging phase a quarter of that kernel.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, :8
+
+// Sum over the 16 lanes of every DPP row (lanes 16 r .. 16 r + 15); every lane of the row gets a row total (lanes of
+// one row may differ in the last bit: the rotations associate the four quad sums in rotated order).
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += dpp_f64<kDppXor1>(v); v += dpp_f64<kDppXor2>(v); v += dpp_f64<kDppRor4>(v); v += dpp_f64<kDppRor8>(v);
+    return v;
+}
+// All 64 lanes must be active.  Every lane gets the same value (the four row totals of lanes 0, 16, 32, 48).
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v = row_sum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+    v = fmin(v, dpp_f64<kDppXor1>(v)); v = fmin(v, dpp_f64<kDppXor2>(v));
+    v = fmin(v, dpp_f64<kDppRor4>(v)); v = fmin(v, dpp_f64<kDppRor8>(v));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = fmax(v, dpp_f64<kDppXor1>(v)); v = fmax(v, dpp_f64<kDppXor2>(v));
+    v = fmax(v, dpp_f64<kDppRor4>(v)); v = fmax(v, dpp_f64<kDppRor8>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // Deterministic block sum (fixed association order): wave shuffle tree, then waves in index order.
@@ -35,6 +71,25 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 #pragma unroll
     for (int w = 0; w < NT / kWave; ++w) r += red[w];
     return r;
+}
+
+// Three deterministic block sums with one barrier pair.  `red` holds 3 * NT/64 doubles.
+template <int NT>
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red)
+{
+    constexpr int NW = NT / kWave;
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[w] = a; red[NW + w] = b; red[2 * NW + w] = c;
+    }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0, rc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { ra += red[w]; rb += red[NW + w]; rc += red[2 * NW + w]; }
+    a = ra; b = rb; c = rc;
+    __syncthreads();
 }
 
 // ---- AS241 (Wichura 1988) PPND16: z = Phi^-1(p) -----------------------------------------------

@@ -30,15 +30,10 @@
 #pragma once
 #include "mcr_device.hpp"
 
-#ifndef MCR_ACOV_LPL
-#define MCR_ACOV_LPL 8
-#endif
-
 namespace mcr {
 
 constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (1024 for chains of <= 1024 draws)
 constexpr int kLag1 = 64;       // tier 1: lags 0 .. 63 (a multiple of 8, at most 64: one lag per lane in k_diag_combine)
-constexpr int kLpl1 = MCR_ACOV_LPL;  // lags per lane of tier 1's register tile (8 x 8 or 8 x 16)
 constexpr int kSegRec = kLag1 + 8;   // doubles per tier-1 record: the lag products + 7 scalars
 constexpr int kMoreBlocks = 3;  // tier 2: lags 64 .. 64 + 64*3 - 1 = 255
 constexpr int kLag2 = kLag1 + 64 * kMoreBlocks;   // first lag of tier 3
@@ -55,25 +50,6 @@ __device__ __forceinline__ double zdec(const double* __restrict__ ztab, u32 code
 {
     const u32 cmax = (u32)(2 * M - 1);
     return ztab[code < cmax ? code : cmax];
-}
-
-// Three deterministic block sums with one barrier pair.  `red` holds 3 * NT/64 doubles.
-template <int NT>
-__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red)
-{
-    constexpr int NW = NT / kWave;
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        red[w] = a; red[NW + w] = b; red[2 * NW + w] = c;
-    }
-    __syncthreads();
-    double ra = 0.0, rb = 0.0, rc = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { ra += red[w]; rb += red[NW + w]; rc += red[2 * NW + w]; }
-    a = ra; b = rb; c = rc;
-    __syncthreads();
 }
 
 // One block of LPL * LG lags of raw products for a staged segment, accumulated into the lane's LPL registers.
@@ -138,19 +114,35 @@ __device__ __forceinline__ void seg_reduce(double (&acc)[LPL], double* tot, doub
     __syncthreads();
 }
 
-template <int NT, int LG, int LPL = 8>
-__device__ __forceinline__ void seg_products(const double* __restrict__ A, const double* __restrict__ B,
-                                             int seglen, double* tot, double* wred)
+// seg_reduce for the 8 x 8 tile with the cross-lane part on DPP and the LDS: the two phases that share a DPP row are
+// added with one row rotation, the four rows of every wave go to `scr` (NT / 64 * 4 * 64 doubles; it may alias the
+// staged segment, which is dead by then) and 64 threads add them.  No ds_bpermute.  All NT threads must call it.
+template <int NT>
+__device__ __forceinline__ void seg_reduce_rows(double (&acc)[8], double* tot, double* scr)
 {
-    double acc[LPL];
+    constexpr int NW = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane & 7, row = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < LPL; ++i) acc[i] = 0.0;
-    seg_accumulate<NT, LG, LPL>(A, B, seglen, acc);
-    seg_reduce<NT, LG, LPL>(acc, tot, wred);
+    for (int li = 0; li < 8; ++li) acc[li] += dpp_f64<kDppRor8>(acc[li]);
+    __syncthreads();  // scr / tot may still be in use
+    if ((lane & 8) == 0) {
+#pragma unroll
+        for (int li = 0; li < 8; ++li) scr[(w * 4 + row) * 64 + g * 8 + li] = acc[li];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < NW * 4; ++r) t += scr[r * 64 + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
 }
 
 // FIRST == true : lags 0..kLag1-1 + the segment's sums (record of kSegRec doubles), every pair.
-// FIRST == false: lags kLag1..kLag1+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only.
+// FIRST == false: lags kLag1..kLag1+64*kMoreBlocks-1 (record of 64*kMoreBlocks doubles), flagged pairs only; the
+//                 segment and its 272-draw halo are staged once and serve all three lag blocks.
 // grid (nseg, C, 2 * P); blockIdx.z = 2 * p + kind.
 template <int NT, int SEG, bool FIRST>
 __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, const u32* __restrict__ zt,
@@ -160,11 +152,15 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
 {
     constexpr int NW = NT / kWave;
     static_assert(SEG % 128 == 0, "spans of the widest tile are 128 draws");
-    constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + 80) / 8 * 10;
-    __shared__ __attribute__((aligned(16))) double sB[LB];
-    __shared__ __attribute__((aligned(16))) double sA[FIRST ? 8 : LA];
+    static_assert(kLag1 == 64, "lag blocks are 64 wide");
+    constexpr int WIN = FIRST ? SEG + 80 : SEG + 64 * kMoreBlocks + 80;     // staged window (draws)
+    constexpr int LX = WIN / 8 * 10;                                         // its swizzled length
+    constexpr int NLD = (WIN + NT - 1) / NT;
+    static_assert(LX >= NW * 4 * 64, "the reduction scratch aliases the staged window");
+    __shared__ __attribute__((aligned(16))) double sx[LX];
+    __shared__ __attribute__((aligned(16))) double scr2[FIRST ? 8 : NW * 4 * 64];
     __shared__ double tot[64];
-    __shared__ double wred[NW * 64];
+    __shared__ double wred[NW * 8];
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;
@@ -179,41 +175,43 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     const int seglen = (int)((n - s0 < 0) ? 0 : ((n - s0 < (i64)SEG) ? n - s0 : (i64)SEG));
 
     if (FIRST) {
-        // ---- stage (9 loads in flight per lane) + segment sums; all index tests in 32-bit,
+        // ---- stage (all loads of a lane in flight together) + segment sums; all index tests in 32-bit,
         //      relative to the segment start ----
-        auto rel = [&](i64 x) -> int { const i64 d = x - s0; return (int)(d < 0 ? 0 : (d > SEG + 80 ? SEG + 80 : d)); };
+        auto rel = [&](i64 x) -> int { const i64 d = x - s0; return (int)(d < 0 ? 0 : (d > WIN ? WIN : d)); };
         const int r_load = rel(nload);                      // draws [0, r_load) of the window exist
         const int r_n = rel(n);                             // draws [0, r_n) enter the products
         const int own = (r_load < SEG) ? r_load : SEG;    // this workgroup owns window slots [0, own)
-        const int a0 = (hc > 0) ? rel(0) : 0, a1 = (hc > 0) ? rel(nh) : 0;             // first half
-        const int b0 = (hc > 0) ? rel(hc) : 0, b1 = (hc > 0) ? rel(hc + nh) : 0;        // second half
+        const int own_n = (own < r_n) ? own : r_n;
+        auto clip = [&](int x) -> int { return x < own ? x : own; };
+        const int a0 = (hc > 0) ? clip(rel(0)) : 0, a1 = (hc > 0) ? clip(rel(nh)) : 0;             // first half
+        const int b0 = (hc > 0) ? clip(rel(hc)) : 0, b1 = (hc > 0) ? clip(rel(hc + nh)) : 0;        // second half
         double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0;
         double vmin = INFINITY, vmax = -INFINITY;
-        double v[9];
+        double v[NLD];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
+        for (int u = 0; u < NLD; ++u) {
             const int j = u * NT + tid;
             v[u] = (j < r_load) ? zdec(ztab, zc[s0 + j], M) : 0.0;
         }
+        // The three windows are ranges of j and a wave's 64 slots are consecutive: a wave that lies wholly inside (or
+        // outside) a window -- all but a handful -- decides that with scalar compares and adds without per-lane masks.
+        const int jw0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+#define MCR_IN_WINDOW(lo, hi, BODY)                                                        \
+        if (jw >= (lo) && jw + 64 <= (hi)) { BODY }                                        \
+        else if (jw + 64 > (lo) && jw < (hi)) { if (j >= (lo) && j < (hi)) { BODY } }
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int j = u * NT + tid;
-            if (j < SEG + 80) {
-                const double x = v[u];
-                if (j < own) {
-                    if (j < r_n) { S += x; vmin = fmin(vmin, x); vmax = fmax(vmax, x); }
-                    if (j >= a0 && j < a1) { S0 += x; Q0 = fma(x, x, Q0); }
-                    if (j >= b0 && j < b1) { S1 += x; Q1 = fma(x, x, Q1); }
-                }
-                sB[pos8(j)] = (j < r_n) ? x : 0.0;
-            }
+        for (int u = 0; u < NLD; ++u) {
+            const int jw = u * NT + jw0, j = u * NT + tid;
+            const double x = v[u];
+            MCR_IN_WINDOW(0, own_n, S += x; vmin = fmin(vmin, x); vmax = fmax(vmax, x);)
+            MCR_IN_WINDOW(a0, a1, S0 += x; Q0 = fma(x, x, Q0);)
+            MCR_IN_WINDOW(b0, b1, S1 += x; Q1 = fma(x, x, Q1);)
+            if (j < WIN) sx[pos8(j)] = (j < r_n) ? x : 0.0;
         }
-        // one barrier pair for the five sums and min / max
+#undef MCR_IN_WINDOW
+        // one barrier for the five sums and min / max
         S = wave_sum(S); S0 = wave_sum(S0); Q0 = wave_sum(Q0); S1 = wave_sum(S1); Q1 = wave_sum(Q1);
-        for (int o = 32; o > 0; o >>= 1) {
-            vmin = fmin(vmin, __shfl_xor(vmin, o, kWave));
-            vmax = fmax(vmax, __shfl_xor(vmax, o, kWave));
-        }
+        vmin = wave_min(vmin); vmax = wave_max(vmax);
         if ((tid & 63) == 0) {
             double* q = wred + (tid >> 6) * 8;
             q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = vmin; q[6] = vmax;
@@ -229,22 +227,37 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
             r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
             r[SG_MIN] = vmin; r[SG_MAX] = vmax;
         }
-        seg_products<NT, kLag1 / kLpl1, kLpl1>(sB, sB, seglen, tot, wred);
+        double acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+        seg_accumulate<NT, 8, 8>(sx, sx, seglen, acc);
+        seg_reduce_rows<NT>(acc, tot, sx);          // the staged window is dead after the barrier inside
         if (tid < kLag1) r[tid] = tot[tid];
     } else {
+        double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
         if (seglen == 0) {   // nothing of [0, n) in this segment: zero record
-            double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
             for (int j = tid; j < 64 * kMoreBlocks; j += NT) r[j] = 0.0;
             return;
         }
-        for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
-        double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
+        double v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int j = u * NT + tid;
+            v[u] = (j < WIN && s0 + j < n) ? zdec(ztab, zc[s0 + j], M) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int j = u * NT + tid;
+            if (j < WIN) sx[pos8(j)] = v[u];
+        }
+        __syncthreads();
         for (int blk = 0; blk < kMoreBlocks; ++blk) {
-            const i64 lb = kLag1 + 64 * blk;
-            __syncthreads();
-            for (int j = tid; j < SEG + 80; j += NT) { const i64 g = s0 + lb + j; sB[pos8(j)] = (g < n) ? zdec(ztab, zc[g], M) : 0.0; }
-            __syncthreads();
-            seg_products<NT, 8>(sA, sB, seglen, tot, wred);
+            const int lb = kLag1 + 64 * blk;
+            double acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+            seg_accumulate<NT, 8, 8>(sx, sx + 10 * (lb >> 3), seglen, acc);
+            seg_reduce_rows<NT>(acc, tot, scr2);
             if (tid < 64) r[blk * 64 + tid] = tot[tid];
         }
     }

@@ -95,13 +95,13 @@ __global__ void k_two_sample_final(const double* __restrict__ part, int nblk, i6
     w1[p] = s;
 }
 
-// Non-finite draws seen by k_tile_sort (third entry of its per-tile partials), summed per parameter.
+// Non-finite draws seen by k_tile_sort (fourth entry of its per-tile partials), summed per parameter.
 __global__ void k_bad_count(const double* __restrict__ part, int ntiles, i64 P, double* __restrict__ bad)
 {
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     double b = 0.0;
-    for (int t = 0; t < ntiles; ++t) b += part[(p * ntiles + t) * 4 + 2];
+    for (int t = 0; t < ntiles; ++t) b += part[(p * ntiles + t) * kMomRec + 3];
     bad[p] = b;
 }
 

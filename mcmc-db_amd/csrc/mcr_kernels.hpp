@@ -128,36 +128,50 @@ __global__ __launch_bounds__(256) void k_ingest_transpose(const T* __restrict__ 
 // np.std(ddof=0) (src/mcmc_ref/backends_numpy.py:41-42), pc.mean / pc.stddev (backends_arrow.py:38-39),
 // compute_basic_stats (compare.py:58-64) -- to a few ulp even when a chain starts far from its bulk (an unconverged
 // `actual` handed to compare()): the cancellation is bounded by the spread INSIDE a slice, not by |first draw - mean|.
-// part[(p*S + s)*4 + {0,1,2,3}] = slice mean, slice M2, non-finite count, slice length.
+// part[(p*S + s)*kMomRec + {0..4}] = slice pivot K, slice mean - K, slice M2 (about its mean), non-finite count, slice
+// length.  The mean travels as the pair (K, mean - K): rounded to one double it would carry an error of ulp(mean) / 2,
+// which Chan's update multiplies by the distance between slice means -- a relative error of eps |mean| / sigma /
+// sqrt(slice) in the variance, 1e-12 for draws of spread 1e-6 around 3.
 // rows variant: grid (S, P); the block streams a contiguous slice of X[p][.] with 16-byte loads.
 // ------------------------------------------------------------------------------------------------
+constexpr int kMomRec = 5;
+
 __device__ __forceinline__ void store_slice_moments(double* o, double K, double s1, double s2, double bad, double n)
 {
-    const double dm = (n > 0.0) ? s1 / n : 0.0;
+    const double dm = (n > 0.0) ? s1 / n : 0.0;         // s1 = sum (x - K), s2 = sum (x - K)^2
     double m2 = s2 - s1 * dm;
     if (!(m2 >= 0.0) && !isnan(m2)) m2 = 0.0;          // tiny negative from rounding; NaN / +inf pass through
-    o[0] = K + dm; o[1] = m2; o[2] = bad; o[3] = n;
+    o[0] = K; o[1] = dm; o[2] = m2; o[3] = bad; o[4] = n;
 }
 
 // (mean, M2, bad) of a parameter from its S slice records (fixed order): Chan et al.'s combination
-//     M2 = sum_s M2_s + sum_s n_s (mean_s - mean)^2,  mean = m_0 + sum_s n_s (mean_s - m_0) / N.
+//     M2 = sum_s M2_s + sum_s n_s (mean_s - mean)^2,  mean = m_0 + sum_s n_s (mean_s - m_0) / N,
+// with every mean difference formed as (K_s - K_0) + (dm_s - dm_0): the pivots of slices of one parameter lie close
+// together, so the first term is exact, and the second is a difference of small corrections.
 __device__ __forceinline__ void merge_slice_moments(const double* __restrict__ rec, int S, double& mean, double& m2,
                                                     double& bad, double& n)
 {
-    const double m0 = rec[0];
+    const double K0 = rec[0], d0 = rec[1];
     double acc = 0.0, N = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) { const double* o = rec + (i64)s * 4; acc += o[3] * (o[0] - m0); N += o[3]; b += o[2]; }
-    const double mu = (N > 0.0) ? m0 + acc / N : NAN;
+    for (int s = 0; s < S; ++s) {
+        const double* o = rec + (i64)s * kMomRec;
+        acc += o[4] * ((o[0] - K0) + (o[1] - d0)); N += o[4]; b += o[3];
+    }
+    const double mr = (N > 0.0) ? acc / N : NAN;        // the mean, relative to K0 + d0
     double q = 0.0;
-    for (int s = 0; s < S; ++s) { const double* o = rec + (i64)s * 4; const double d = o[0] - mu; q += o[1]; q = fma(o[3] * d, d, q); }
-    mean = mu; m2 = q; bad = b; n = N;
+    for (int s = 0; s < S; ++s) {
+        const double* o = rec + (i64)s * kMomRec;
+        const double d = ((o[0] - K0) + (o[1] - d0)) - mr;
+        q += o[2]; q = fma(o[4] * d, d, q);
+    }
+    mean = K0 + (d0 + mr); m2 = q; bad = b; n = N;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i64 M, i64 pstride,
                                                       double* __restrict__ part, int S)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     const i64 p = blockIdx.y;
     const int s = blockIdx.x;
     const T* x = X + p * pstride;
@@ -205,10 +219,8 @@ __global__ __launch_bounds__(256) void k_moments_rows(const T* __restrict__ X, i
         scalar_from = b + nvec * V;
     }
     for (i64 j = scalar_from + threadIdx.x; j < e; j += 256) acc1((double)x[j]);
-    s1 = block_sum<256>(s1, red);
-    s2 = block_sum<256>(s2, red);
-    bad = block_sum<256>(bad, red);
-    if (threadIdx.x == 0) store_slice_moments(part + (p * S + s) * 4, K, s1, s2, bad, (double)(e > b ? e - b : 0));
+    block_sum3<256>(s1, s2, bad, red);
+    if (threadIdx.x == 0) store_slice_moments(part + (p * S + s) * kMomRec, K, s1, s2, bad, (double)(e > b ? e - b : 0));
 }
 
 // strided variant ([C][N][P]-like tensors, stride_p == 1): lanes run along p, each thread owns one
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void k_moments_cols(const T* __restrict__ src,
     sh[0][ty][tx] = s1; sh[1][ty][tx] = s2; sh[2][ty][tx] = bad;
     __syncthreads();
     if (ty == 0 && p < P)
-        store_slice_moments(part + (p * S + s) * 4, K, sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx],
+        store_slice_moments(part + (p * S + s) * kMomRec, K, sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx],
                             sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx],
                             sh[2][0][tx] + sh[2][1][tx] + sh[2][2][tx] + sh[2][3][tx], (double)(e > b ? e - b : 0));
 }
@@ -251,7 +263,7 @@ __global__ void k_moments_final(const double* __restrict__ part, int S, i64 P, d
     const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     double mu, m2, b, n;
-    merge_slice_moments(part + p * S * 4, S, mu, m2, b, n);
+    merge_slice_moments(part + p * S * kMomRec, S, mu, m2, b, n);
     double var = m2 / n;
     if (isinf(m2)) var = INFINITY;          // squares overflowed: inf like np.std
     else if (!(var >= 0.0)) var = 0.0;
@@ -412,15 +424,11 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
     for (int i = 0; i < VT; ++i) s1 += (tid * VT + i < count) ? k[i] : 0.0;
     s1 = block_sum<NT>(s1, red);
     const double mt = s1 / (double)count;
-    double s2 = 0.0;
+    double s2 = 0.0, e1 = 0.0;       // second pass about mt; e1 = sum (x - mt) is what rounding left of the mean
 #pragma unroll
-    for (int i = 0; i < VT; ++i) { const double d = (tid * VT + i < count) ? k[i] - mt : 0.0; s2 = fma(d, d, s2); }
-    s2 = block_sum<NT>(s2, red);
-    bad = block_sum<NT>(bad, red);
-    if (tid == 0) {
-        double* o = part + (p * ntiles + tile) * 4;
-        o[0] = mt; o[1] = s2; o[2] = bad; o[3] = (double)count;
-    }
+    for (int i = 0; i < VT; ++i) { const double d = (tid * VT + i < count) ? k[i] - mt : 0.0; s2 = fma(d, d, s2); e1 += d; }
+    block_sum3<NT>(s2, e1, bad, red);
+    if (tid == 0) store_slice_moments(part + (p * ntiles + tile) * kMomRec, mt, e1, s2, bad, (double)count);
 }
 
 // Tie runs of a sorted LDS array by scans instead of per-element searches (uniform cost however heavy
@@ -1012,7 +1020,7 @@ __device__ __forceinline__ void finalize_param(const double* __restrict__ part, 
                                                i64 P, int C, double* __restrict__ res, i64 p)
 {
     double mu, m2, b, n;
-    merge_slice_moments(part + p * S * 4, S, mu, m2, b, n);
+    merge_slice_moments(part + p * S * kMomRec, S, mu, m2, b, n);
     double var = m2 / (double)M;
     if (isinf(m2)) var = INFINITY;          // squares overflowed: inf like np.std
     else if (!(var >= 0.0)) var = 0.0;

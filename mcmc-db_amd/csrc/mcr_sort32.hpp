@@ -129,15 +129,11 @@ __global__ __launch_bounds__(NT) void k_tile_sort32(const float* __restrict__ X,
     for (int i = 0; i < VT; ++i) s1 += (tid * VT + i < count) ? key_value(rec_key(r[i])) : 0.0;
     s1 = block_sum<NT>(s1, red);
     const double mt = s1 / (double)count;
-    double s2 = 0.0;
+    double s2 = 0.0, e1 = 0.0;
 #pragma unroll
-    for (int i = 0; i < VT; ++i) { const double d = (tid * VT + i < count) ? key_value(rec_key(r[i])) - mt : 0.0; s2 = fma(d, d, s2); }
-    s2 = block_sum<NT>(s2, red);
-    bad = block_sum<NT>(bad, red);
-    if (tid == 0) {
-        double* o = part + (p * ntiles + tile) * 4;
-        o[0] = mt; o[1] = s2; o[2] = bad; o[3] = (double)count;
-    }
+    for (int i = 0; i < VT; ++i) { const double d = (tid * VT + i < count) ? key_value(rec_key(r[i])) - mt : 0.0; s2 = fma(d, d, s2); e1 += d; }
+    block_sum3<NT>(s2, e1, bad, red);
+    if (tid == 0) store_slice_moments(part + (p * ntiles + tile) * kMomRec, mt, e1, s2, bad, (double)count);
 }
 
 // ------------------------------------------------------------------------------------------------
