@@ -416,7 +416,7 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
                (const unsigned*)nullptr, a.rec);
     }
-    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64), (size_t)6 * a.C * 8, (const u32*)a.zb,
+    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64u * (unsigned)(a.C < kCombineWaves ? a.C : kCombineWaves)), (size_t)6 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate,
            a.long_count);
     // tier 2 for pairs whose first negative rho lies beyond lag 63 (others exit at once)
@@ -656,10 +656,10 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
     }
     // 3. order statistics
     if (use_records(a)) {
-        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
+        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
                (const u64*)kin, M, pc, a.q, a.d_res, a.split);
     } else {
-        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<double>, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0,
+        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<double>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
                (const double*)kin, M, pc, a.q, a.d_res, a.split);
     }
     if (a.do_diag) {

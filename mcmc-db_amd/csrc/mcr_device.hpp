@@ -58,6 +58,28 @@ __device__ __forceinline__ double wave_max(double v)
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
+// Exclusive prefix sums over the 64 lanes of a wave, plus the wave total: the six-step DPP scan (row_shr 1, 2, 4, 8
+// inside the rows of 16, then row_bcast 15 / 31 carry the row totals into the rows above).  All 64 lanes active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_or_zero(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);       // lanes without a source (shifted in, masked rows) get +0.0
+}
+__device__ __forceinline__ double wave_excl_scan(double v, double& total)
+{
+    double incl = v;
+    incl += dpp_f64_or_zero<0x111, 0xf>(incl);     // row_shr:1
+    incl += dpp_f64_or_zero<0x112, 0xf>(incl);     // row_shr:2
+    incl += dpp_f64_or_zero<0x114, 0xf>(incl);     // row_shr:4
+    incl += dpp_f64_or_zero<0x118, 0xf>(incl);     // row_shr:8
+    incl += dpp_f64_or_zero<0x142, 0xa>(incl);     // row_bcast:15 -> rows 1, 3
+    incl += dpp_f64_or_zero<0x143, 0xc>(incl);     // row_bcast:31 -> rows 2, 3
+    total = readlane_f64(incl, 63);
+    return incl - v;
+}
+
 // Deterministic block sum (fixed association order): wave shuffle tree, then waves in index order.
 // `red` is LDS scratch of NT/64 doubles.  Every thread gets the result.
 template <int NT>

@@ -263,24 +263,16 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     }
 }
 
-// Exclusive prefix sums over the 64 lanes of a wave, plus the wave total.
-__device__ __forceinline__ double wave_excl_scan(double v, double& total)
-{
-    const int lane = threadIdx.x & 63;
-    double incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, kWave); if (lane >= o) incl += t; }
-    total = __shfl(incl, 63, kWave);
-    return incl - v;
-}
-
 // Per-chain state kept between the combine kernels.
 constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), -
 // Per-pair scan state: rho_sum, terms, var_hat, decided (tier 3)
 constexpr int kPairState = 4;
 
-// One wave per (parameter, kind).  grid (P, 2), block 64.  Also resets the tier-3 list of this call.
-__global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb, const u32* __restrict__ zt,
+// One workgroup per (parameter, kind), one wave per chain (kCombineWaves at most; the chains' record sums, head / tail
+// scans and loads are independent, so this divides the latency chain of the kernel by the number of chains), then wave 0
+// alone.  grid (P, 2), block 64 * min(C, kCombineWaves).  Also resets the tier-3 list of this call.
+constexpr int kCombineWaves = 8;
+__global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                                      const double* __restrict__ ztab, i64 M,
                                                      const i64* __restrict__ off, int C, i64 n, i64 nh,
                                                      int nseg, const double* __restrict__ rec,
@@ -293,7 +285,8 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
     double* cq = cm + C;                             // C   sum (z - mean)^2
     double* hm = cq + C;                             // 2C  half means
     double* hq = hm + 2 * C;                         // 2C  half sums of squared deviations
-    const int lane = threadIdx.x;
+    __shared__ double wcov[kCombineWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = (int)(blockDim.x >> 6);
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
@@ -301,10 +294,10 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-    if (pk == 0 && lane == 0) *long_count = 0u;     // k_diag_combine2 (a later launch on this stream) appends to the list
+    if (pk == 0 && threadIdx.x == 0) *long_count = 0u;     // k_diag_combine2 (a later launch on this stream) appends to the list
 
-    double covsum = 0.0;   // lane l: sum over chains of sum_i (z_i - m)(z_{i+l} - m)
-    for (int c = 0; c < C; ++c) {
+    double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
+    for (int c = w; c < C; c += W) {
         const double* R = rec + ((pk * C + c) * (i64)nseg) * kSegRec;
         double Pl = 0.0, S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0, Q = 0.0;
         double vmin = INFINITY, vmax = -INFINITY;
@@ -335,7 +328,10 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
             cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = h32; cs[4] = t32;
         }
     }
+    wcov[w][lane] = covsum;
     __syncthreads();
+    if (w != 0) return;
+    for (int ww = 1; ww < W; ++ww) covsum += wcov[ww][lane];      // fixed order
     __shared__ double bc[2];   // var_hat, mode (0: NaN, 1: var_hat == 0, 2: scan)
     if (lane == 0) {
         // ---- split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped ----
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(64) void k_diag_combine(const u32* __restrict__ zb,
         }
         bc[0] = vh; bc[1] = mode;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();         // only wave 0 is left; a wave's LDS accesses execute in order
     const double vh = bc[0];
     const int mode = (int)bc[1];
     // ---- rho terms of lags 1..kLag1-1, one per lane; the first negative one stops the sum
@@ -441,6 +437,8 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     if (kind == 0 && threadIdx.x == 0) finalize_param(part, ntiles, M, P, C, res, p);
     if (more[pk] == 0u) return;
     __shared__ double ctl[3];
+    constexpr int NW2 = 16;
+    __shared__ double wcov[NW2][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u32* z = (kind ? zt : zb) + p * M;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
@@ -450,7 +448,7 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     const double vhat = state[pk * kPairState + 2];
     bool stop = false;
 
-    // ---- lags kLag1..kLag2-1: wave 0 combines the records block by block ----
+    // ---- lags kLag1..kLag2-1, block by block ----
     // hb[c] / tb[c]: running sums of the first / last `lb` draws of chain c (head / tail bases)
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     double* hb = reinterpret_cast<double*>(smem2);
@@ -460,15 +458,16 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     for (int blk = 0; blk < kMoreBlocks && !stop; ++blk) {
         const i64 lb = kLag1 + 64 * blk;
         if (lb >= n) break;
-        if (w == 0) {
+        {   // one wave per chain (the chains' scans and record sums are independent), then wave 0 alone
             double covsum = 0.0;
-            for (int c = 0; c < C; ++c) {
+            for (int c = w; c < C; c += NW2) {
                 const double* cs = chstate + (pk * C + c) * kChState;
                 const u32* zc = z + off[c];
                 double th, tt;
                 const double hx = wave_excl_scan((lb + lane < n) ? zdec(ztab, zc[lb + lane], M) : 0.0, th);
                 const double tx = wave_excl_scan((lb + lane < n) ? zdec(ztab, zc[n - 1 - (lb + lane)], M) : 0.0, tt);
                 const double head = hb[c] + hx, tail = tb[c] + tx;   // sums of the first / last (lb + lane) draws
+                __builtin_amdgcn_wave_barrier();
                 if (lane == 0) { hb[c] += th; tb[c] += tt; }
                 if (cs[2] != 0.0) continue;                       // constant chain: zero deviations
                 const double m = cs[0], S = cs[1];
@@ -478,6 +477,13 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
                 const i64 lag = lb + lane;
                 if (lag < n) covsum += Pl - m * ((S - tail) + (S - head)) + (double)(n - lag) * m * m;
             }
+            wcov[w][lane] = covsum;
+        }
+        __syncthreads();
+        if (w == 0) {
+            double covsum = wcov[0][lane];
+            const int nw = (C < NW2) ? C : NW2;
+            for (int ww = 1; ww < nw; ++ww) covsum += wcov[ww][lane];     // fixed order
             const i64 lag = lb + lane;
             const bool valid = lag < n;
             const double rho = valid ? (covsum / (double)(n - lag)) / ((double)C * vhat) : 0.0;

@@ -945,29 +945,38 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
 // Order statistics from the pooled ascending keys: quantiles (numpy `linear` lerp, which pyarrow's
 // interpolation="linear" agrees with to 1 ulp; src/mcmc_ref/backends_numpy.py:44,
 // backends_arrow.py:40-42), statistics.median (diagnostics.py:97) and the fold split point
-// s = #(x < med).  One thread per parameter.
+// s = #(x < med).  One WAVE per parameter: lane j takes quantile j, and the split point is found by a 64-ary search
+// (64 probes and a ballot per round: three dependent loads for 40 000 draws where a bisection needs sixteen -- the
+// kernel is nothing but that latency chain, and the fold merge waits for it).  grid ceil(P / 4), block 256.
 // ------------------------------------------------------------------------------------------------
 template <typename KT>
-__global__ void k_order_stats(const KT* __restrict__ keys, i64 M, i64 P, QArgs q,
-                              double* __restrict__ res, i64* __restrict__ split)
+__global__ __launch_bounds__(256) void k_order_stats(const KT* __restrict__ keys, i64 M, i64 P, QArgs q,
+                                                     double* __restrict__ res, i64* __restrict__ split)
 {
 #pragma clang fp contract(off)  // the lerp must round like numpy's (separate multiply and add)
-    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const i64 p = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
     const KT* k = keys + p * M;
-    for (int j = 0; j < q.nq; ++j) {
+    if (lane < q.nq) {
+        const int j = lane;
         const i64 lo = q.lo[j], hi = (lo + 1 < M) ? lo + 1 : M - 1;
         const double a = sorted_key(k, lo), b = sorted_key(k, hi), d = b - a, g = q.g[j];
         res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
     }
     const double med = (M & 1) ? sorted_key(k, M / 2) : (sorted_key(k, M / 2 - 1) + sorted_key(k, M / 2)) / 2.0;
-    res[R_MEDIAN * P + p] = med;
-    i64 lo = 0, hi = M;  // first index with k[i] >= med
+    if (lane == 0) res[R_MEDIAN * P + p] = med;
+    i64 lo = 0, hi = M;  // first index with k[i] >= med lies in [lo, hi]
     while (lo < hi) {
-        const i64 mid = (lo + hi) >> 1;
-        if (sorted_key(k, mid) < med) lo = mid + 1; else hi = mid;
+        const i64 step = (hi - lo + 63) / 64;
+        const i64 pos = lo + step * (lane + 1) - 1;                 // ascending probes, the last one at or beyond hi - 1
+        const bool less = (pos < hi) && (sorted_key(k, pos) < med);
+        const i64 cnt = (i64)__popcll(__ballot(less));              // sorted keys: the first cnt probes are below med
+        const i64 nhi = lo + step * (cnt + 1) - 1;                  // probe cnt (if any) is the first one not below
+        lo += step * cnt;
+        hi = (nhi < hi) ? nhi : hi;
     }
-    split[p] = lo;
+    if (lane == 0) split[p] = lo;
 }
 
 // ------------------------------------------------------------------------------------------------
