@@ -67,9 +67,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--windows", type=int, default=5,
-                    help="the K-step timed window is repeated this many times; ms_per_step is the MEDIAN window "
-                         "(a 5 ms region is fragile: ramp-up and drain of the rolling window are ~10 %% of it)")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="number of K-step timed windows (ms_per_step is the MEDIAN window); 0 = repeat until they cover "
+                         "0.3 s of timed work, at least 5 and at most 64 (a 5 ms region is fragile: clock ramp-up, fill "
+                         "and drain of the rolling window)")
     ap.add_argument("--workload", choices=["c1", "c1split", "corpus", "stress"], default="c1")
     ap.add_argument("--chains", type=int, default=4)
     ap.add_argument("--draws", type=int, default=10000)
@@ -129,19 +130,36 @@ class Ranks:
             self.comm.close()
 
 
+MIN_WINDOWS, MAX_WINDOWS, MIN_TIMED_SECONDS = 5, 64, 0.3
+
+
 def timed_windows(a, ranks: Ranks, run) -> tuple[float, list[float], object]:
-    """W warm-up steps, then `windows` timed regions of EXACTLY K steps each, every one bracketed by a barrier +
-    device sync on both sides and clocked as the MAX over ranks.  Returns (median seconds per window, all windows,
-    the last result handle of the last window)."""
+    """W warm-up steps, then timed regions of EXACTLY K steps each, every one bracketed by a barrier + device sync on
+    both sides and clocked as the MAX over ranks.  `--windows N` fixes their number; the default (0) repeats them until
+    they cover MIN_TIMED_SECONDS of timed work (at least MIN_WINDOWS, at most MAX_WINDOWS): a 20-step window is 3.6 ms,
+    and the box needs tens of milliseconds of load before its clocks settle (the first windows of a short run are
+    10 - 20 % slower; all of them are printed).  Returns (median seconds per window, all windows, the last result
+    handle of the last window)."""
     run(a.warmup)
     secs, last = [], None
-    for _ in range(max(1, a.windows)):
+    while True:
         ranks.barrier()
         t0 = time.perf_counter()
         last = run(a.steps)
         ranks.barrier()
-        secs.append(ranks.max(time.perf_counter() - t0))
+        secs.append(ranks.max(time.perf_counter() - t0))          # the same value on every rank
+        if a.windows > 0:
+            if len(secs) >= a.windows:
+                break
+        elif len(secs) >= MAX_WINDOWS or (len(secs) >= MIN_WINDOWS and sum(secs) >= MIN_TIMED_SECONDS):
+            break
     return statistics.median(secs), secs, last
+
+
+def timing_note(a, windows: list[float]) -> str:
+    how = (f"{len(windows)} windows" if a.windows > 0 else
+           f"{len(windows)} windows (repeated until {MIN_TIMED_SECONDS} s of timed work, {MIN_WINDOWS}..{MAX_WINDOWS})")
+    return f"median of {how} of {a.steps} steps, each bracketed by barrier + device sync, MAX over ranks"
 
 
 def hbm_probe(ctx, a) -> dict | None:
@@ -498,7 +516,7 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
                        "layout": a.layout, "statistics": "mean,std,q5,q50,q95,split_rhat,ess_bulk,ess_tail",
                        "sharding": f"independent models, {world} rank(s), RCCL all-gather of summaries (library, no torch)"},
             "validated": valid, "max_rel_err": worst,
-            "timing": f"median of {len(windows)} windows of {a.steps} steps, each bracketed by barrier + device sync, MAX over ranks",
+            "timing": timing_note(a, windows), "ms_per_step_first_window": round(windows[0] / a.steps * 1e3, 5),
             "ms_per_step_windows": [round(s / a.steps * 1e3, 5) for s in windows],
             "ms_per_step_event_pass": elapsed_prof / a.steps * 1e3,
             "pipeline_alg_GBps": value / world * es / 1e9,
