@@ -39,25 +39,24 @@ __device__ __forceinline__ double row_sum(double v)
     v += dpp_f64<kDppXor1>(v); v += dpp_f64<kDppXor2>(v); v += dpp_f64<kDppRor4>(v); v += dpp_f64<kDppRor8>(v);
     return v;
 }
+__device__ __forceinline__ double row_min(double v)
+{
+    v = fmin(v, dpp_f64<kDppXor1>(v)); v = fmin(v, dpp_f64<kDppXor2>(v));
+    v = fmin(v, dpp_f64<kDppRor4>(v)); v = fmin(v, dpp_f64<kDppRor8>(v));
+    return v;
+}
+__device__ __forceinline__ double row_max(double v)
+{
+    v = fmax(v, dpp_f64<kDppXor1>(v)); v = fmax(v, dpp_f64<kDppXor2>(v));
+    v = fmax(v, dpp_f64<kDppRor4>(v)); v = fmax(v, dpp_f64<kDppRor8>(v));
+    return v;
+}
 // All 64 lanes must be active.  Every lane gets the same value (the four row totals of lanes 0, 16, 32, 48).
 __device__ __forceinline__ double wave_sum(double v)
 {
     v = row_sum(v);
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
-__device__ __forceinline__ double wave_min(double v)
-{
-    v = fmin(v, dpp_f64<kDppXor1>(v)); v = fmin(v, dpp_f64<kDppXor2>(v));
-    v = fmin(v, dpp_f64<kDppRor4>(v)); v = fmin(v, dpp_f64<kDppRor8>(v));
-    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-    v = fmax(v, dpp_f64<kDppXor1>(v)); v = fmax(v, dpp_f64<kDppXor2>(v));
-    v = fmax(v, dpp_f64<kDppRor4>(v)); v = fmax(v, dpp_f64<kDppRor8>(v));
-    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
-}
-
 // Exclusive prefix sums over the 64 lanes of a wave, plus the wave total: the six-step DPP scan (row_shr 1, 2, 4, 8
 // inside the rows of 16, then row_bcast 15 / 31 carry the row totals into the rows above).  All 64 lanes active.
 template <int CTRL, int ROW_MASK>

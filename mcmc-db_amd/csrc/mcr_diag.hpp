@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     __shared__ __attribute__((aligned(16))) double sx[LX];
     __shared__ __attribute__((aligned(16))) double scr2[FIRST ? 8 : NW * 4 * 64];
     __shared__ double tot[64];
-    __shared__ double wred[NW * 8];
+    __shared__ double wred[NW * 4 * 8];
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;
@@ -209,23 +209,23 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
             if (j < WIN) sx[pos8(j)] = (j < r_n) ? x : 0.0;
         }
 #undef MCR_IN_WINDOW
-        // one barrier for the five sums and min / max
-        S = wave_sum(S); S0 = wave_sum(S0); Q0 = wave_sum(Q0); S1 = wave_sum(S1); Q1 = wave_sum(Q1);
-        vmin = wave_min(vmin); vmax = wave_max(vmax);
-        if ((tid & 63) == 0) {
-            double* q = wred + (tid >> 6) * 8;
+        // The five sums and min / max: DPP inside the rows of 16 lanes, the 4 NW row results through the LDS, seven
+        // lanes finish (one barrier; no cross-row shuffles).
+        S = row_sum(S); S0 = row_sum(S0); Q0 = row_sum(Q0); S1 = row_sum(S1); Q1 = row_sum(Q1);
+        vmin = row_min(vmin); vmax = row_max(vmax);
+        if ((tid & 15) == 0) {
+            double* q = wred + (tid >> 4) * 8;
             q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = vmin; q[6] = vmax;
         }
         __syncthreads();
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;
-        if (tid == 0) {
-            for (int w = 1; w < NW; ++w) {
-                const double* q = wred + w * 8;
-                S += q[0]; S0 += q[1]; Q0 += q[2]; S1 += q[3]; Q1 += q[4];
-                vmin = fmin(vmin, q[5]); vmax = fmax(vmax, q[6]);
+        if (tid < 7) {
+            double t = wred[tid];
+            for (int w = 1; w < NW * 4; ++w) {
+                const double x = wred[w * 8 + tid];
+                t = (tid < 5) ? t + x : ((tid == 5) ? fmin(t, x) : fmax(t, x));
             }
-            r[SG_S] = S; r[SG_S0] = S0; r[SG_Q0] = Q0; r[SG_S1] = S1; r[SG_Q1] = Q1;
-            r[SG_MIN] = vmin; r[SG_MAX] = vmax;
+            r[SG_S + tid] = t;        // SG_S, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX are consecutive
         }
         double acc[8];
 #pragma unroll
