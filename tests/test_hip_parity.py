@@ -167,6 +167,16 @@ def test_shapes_edge_cases(ctx, oracle):
         got = ctx.summarize(x, "pcn", min_chains=1)
         exp = oracle.summarize(x, "pcn", min_chains=1)
         check_summary(got, exp, what=f"{(P, C, N)}")
+    # the order-statistics kernel: one wave per parameter (blocks of four), lane j = quantile j (32 at most), 64-ary
+    # search for the fold split -- parameter counts off the block size, every lane busy, ties across the median
+    qs = np.linspace(0.0, 1.0, 32)
+    for (P, C, N) in [(7, 4, 16), (5, 2, 33), (9, 4, 1031), (6, 3, 4099)]:
+        x = rng.normal(size=(P, C, N))
+        x[1] = np.round(x[1])                                   # heavy ties, the median inside a long run
+        x[2, :, : N // 2] = 0.5                                  # half of the draws equal
+        got = ctx.summarize(x, "pcn", min_chains=1, quantiles=qs)
+        exp = oracle.summarize(x, "pcn", min_chains=1, quantiles=qs)
+        check_summary(got, exp, what=f"32 quantiles {(P, C, N)}")
     # empty tensors
     got = ctx.summarize(np.zeros((2, 4, 0)), "pcn")
     assert np.isnan(got["mean"]).all() and np.isnan(got["rhat"]).all() and np.isnan(got["ess_bulk"]).all()
