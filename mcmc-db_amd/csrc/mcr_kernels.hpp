@@ -554,19 +554,24 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
     const int ca = (int)(ai1 - ai0), cb = (int)((d1 - ai1) - bi0);
     const int total = ca + cb;
 
-    for (int e = tid; e < total; e += NT) {
-        double v; u32 id;
-        if (e < ca) {
-            const i64 g = FOLD ? abase - (ai0 + e) : abase + ai0 + e;
-            v = FOLD ? med - KEY(g) : KEY(g);
-            id = POS(g);
-        } else {
-            const i64 g = bbase + bi0 + (e - ca);
-            v = FOLD ? KEY(g) - med : KEY(g);
-            id = POS(g);
+    {   // gather the two runs: slot e = j * NT + tid; all VT (key, position) loads of a lane are issued before the first
+        // LDS store waits for one (slots at or beyond `total` read element 0 and are not stored)
+        double gv[VT]; u32 gi[VT];
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            const bool inA = e < ca;
+            i64 g = inA ? (FOLD ? abase - (ai0 + e) : abase + ai0 + e) : bbase + bi0 + (e - ca);
+            g = (e < total) ? g : 0;
+            const double x = KEY(g);
+            gv[j] = FOLD ? (inA ? med - x : x - med) : x;
+            gi[j] = POS(g);
         }
-        skey[pos16(e)] = v;
-        sidx[pos16(e)] = (IdxT)id;
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            if (e < total) { skey[pos16(e)] = gv[j]; sidx[pos16(e)] = (IdxT)gi[j]; }
+        }
     }
     __syncthreads();
 

@@ -164,7 +164,20 @@ __global__ __launch_bounds__(NT) void k_merge32(const u64* __restrict__ rin, u64
     const i64 ai0 = sh[0], ai1 = sh[1], bi0 = d0 - ai0;
     const int ca = (int)(ai1 - ai0), cb = (int)((d1 - ai1) - bi0);
     const int total = ca + cb;
-    for (int e = tid; e < total; e += NT) srec[pos16(e)] = (e < ca) ? rp[abase + ai0 + e] : rp[bbase + bi0 + (e - ca)];
+    {   // all VT loads of a lane in flight before the first LDS store (slots beyond `total` read record 0, not stored)
+        u64 gr[VT];
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            const i64 g = (e < ca) ? abase + ai0 + e : bbase + bi0 + (e - ca);
+            gr[j] = rp[(e < total) ? g : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            const int e = j * NT + tid;
+            if (e < total) srec[pos16(e)] = gr[j];
+        }
+    }
     __syncthreads();
     const int diag = (tid * VT < total) ? tid * VT : total;
     const int nout = (total - diag < VT) ? total - diag : VT;
