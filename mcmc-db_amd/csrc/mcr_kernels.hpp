@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
     for (int i = 0; i < VT; ++i) {
         const int e = tid * VT + i;
         skey[pos16(e)] = k[i];
-        sidx[pos16(e)] = (IdxT)ix[i];
+        sidx[posi(e)] = (IdxT)ix[i];
     }
     __syncthreads();
 
@@ -395,20 +395,20 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
         int srcs[VT];
         serial_merge<VT>(skey, a0, run, b0, run, ai, diag - ai, VT, k, srcs);
 #pragma unroll
-        for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+        for (int i = 0; i < VT; ++i) ix[i] = sidx[posi(srcs[i])];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < VT; ++i) {
             const int e = tid * VT + i;
             skey[pos16(e)] = k[i];
-            sidx[pos16(e)] = (IdxT)ix[i];
+            sidx[posi(e)] = (IdxT)ix[i];
         }
         __syncthreads();
     }
 
     for (int e = tid; e < count; e += NT) {
         keys[p * M + base + e] = skey[pos16(e)];
-        idx[p * M + base + e] = sidx[pos16(e)];
+        idx[p * M + base + e] = sidx[posi(e)];
     }
     // regular samples (every 64th order statistic of the tile) for the exact bucket partition
     if (samp != nullptr && tid < T / 64) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
 #pragma unroll
         for (int j = 0; j < VT; ++j) {
             const int e = j * NT + tid;
-            if (e < total) { skey[pos16(e)] = gv[j]; sidx[pos16(e)] = (IdxT)gi[j]; }
+            if (e < total) { skey[pos16(e)] = gv[j]; sidx[posi(e)] = (IdxT)gi[j]; }
         }
     }
     __syncthreads();
@@ -585,20 +585,20 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
     u32 ix[VT];
     serial_merge<VT>(skey, 0, ca, ca, cb, ai, diag - ai, nout, k, srcs);
 #pragma unroll
-    for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+    for (int i = 0; i < VT; ++i) ix[i] = sidx[posi(srcs[i])];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
         if (i < nout) {
             skey[pos16(diag + i)] = k[i];
-            sidx[pos16(diag + i)] = (IdxT)ix[i];
+            sidx[posi(diag + i)] = (IdxT)ix[i];
         }
     }
     __syncthreads();
     if (z == nullptr) {
         for (int e = tid; e < total; e += NT) {
             kout[p * M + o0 + e] = skey[pos16(e)];
-            iout[p * M + o0 + e] = sidx[pos16(e)];
+            iout[p * M + o0 + e] = sidx[posi(e)];
         }
         return;
     }
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
             i64 gs = d0 + rs[i], ge = d0 + re[i];
             if (ext0 && v == vfirst) gs = gfirst;
             if (ext1 && v == vlast) ge = glast;
-            const u32 t_idx = min((u32)sidx[pos16(e)], (u32)(M - 1));     // stale order after a rejected (NaN) partition
+            const u32 t_idx = min((u32)sidx[posi(e)], (u32)(M - 1));     // stale order after a rejected (NaN) partition
             z[p * M + t_idx] = (u32)(gs + ge);            // code of the tie run: rank = (code + 1) / 2
         }
     }
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
 #pragma unroll
         for (int j = 0; j < VT; ++j) {
             const int e = j * NT + tid;
-            if (e < padded) { skey[pos16(e)] = gv[j]; sidx[pos16(e)] = gi[j]; }
+            if (e < padded) { skey[pos16(e)] = gv[j]; sidx[posi(e)] = gi[j]; }
         }
     }
     __syncthreads();
@@ -882,20 +882,20 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
                 const int ai = merge_path32(A, na, Bf, nb, diag);
                 serial_merge<VT>(skey, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
 #pragma unroll
-                for (int i = 0; i < VT; ++i) ix[i] = sidx[pos16(srcs[i])];
+                for (int i = 0; i < VT; ++i) ix[i] = sidx[posi(srcs[i])];
             }
         }
         __syncthreads();
         if (moved) {
 #pragma unroll
-            for (int i = 0; i < VT; ++i) { skey[pos16(chunk0 + i)] = kk[i]; sidx[pos16(chunk0 + i)] = (IdxT)ix[i]; }
+            for (int i = 0; i < VT; ++i) { skey[pos16(chunk0 + i)] = kk[i]; sidx[posi(chunk0 + i)] = (IdxT)ix[i]; }
         }
         __syncthreads();
     }
     // pooled ascending order out
     for (int e = tid; e < total; e += NT) {
         kout[p * M + obase + e] = skey[pos16(e)];
-        iout[p * M + obase + e] = sidx[pos16(e)];
+        iout[p * M + obase + e] = sidx[posi(e)];
     }
     if (z == nullptr || total == 0) return;
     // Do the first / last tie runs continue in a neighbouring bucket?  Look at the element just
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
             i64 gs = obase + rs[i], ge = obase + re[i];
             if (ext0 && v == vfirst) gs = sedge[0];
             if (ext1 && v == vlast) ge = sedge[3];
-            z[p * M + min((u32)sidx[pos16(e)], (u32)(M - 1))] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
+            z[p * M + min((u32)sidx[posi(e)], (u32)(M - 1))] = (u32)(gs + ge);   // code of the tie run: rank = (code + 1) / 2
         }
     }
 }
