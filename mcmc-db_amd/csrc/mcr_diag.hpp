@@ -16,10 +16,15 @@
 //           is applied in the combine step, which makes the pass single-sweep, independent of chain length
 //           (any n) and fine-grained enough to fill 256 CUs.  Lag 0 gives sum z^2, so variances cost nothing
 //           extra.  (Measured with 32 lags instead: the pass got 8 % shorter -- staging, not the FMAs, is most of
-//           it -- while three times as many C1 pairs needed tier 2; 64 stays.)
-//           k_diag_combine: one wave per pair: per-chain means / variances, split R-hat, var_hat, the rho
-//           terms of lags 1..63; pairs without a negative rho so far are flagged.
-//   tier 2  k_acov_seg<!FIRST> + k_diag_combine2: flagged pairs only (the others exit at once), lags 64..255.
+//           it -- while three times as many C1 pairs needed tier 2; 64 stays.  Measured on the matrix cores
+//           instead, the lag products being the diagonals of a [16 x Q] x [Q x 80] product of the segment cut into
+//           rows of 16: slower, fp64 MFMA has the rate of the fp64 VALU FMA and a fifth of the tile is off the
+//           diagonals -- DESIGN.md section 4.)  Everything across lanes is DPP or one pass through the LDS.
+//           k_diag_combine: one workgroup per pair, one wave per chain (record sums, head / tail prefix scans),
+//           then wave 0: split R-hat, var_hat, the rho terms of lags 1..63; pairs without a negative rho so far
+//           are flagged.
+//   tier 2  k_acov_seg<!FIRST> + k_diag_combine2: flagged pairs only (the others exit at once), lags 64..255; the
+//           segment and a 272-draw halo are staged once for the three 64-lag blocks.
 //   tier 3  k_acov_long + k_diag_long_scan, in rounds [256, 16384), [16384, 262144), ...: the pairs still undecided
 //           (sticky chains: a random walk truncates after thousands of lags) are compacted into a list, their
 //           deviations z - mean are materialised once, and EVERY CU works on them: one workgroup per
