@@ -298,6 +298,86 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 #undef MCR_CE
 }
 
+// The first two merge levels of the tile sort (16 -> 32 -> 64 sorted draws) without the LDS: bitonic merges across 2 and 4
+// lanes.  Lane L of a group holds the sorted draws 16 L .. 16 L + 15 of the group's run in its registers.  To merge the
+// ascending runs A and B of a group, draw e of A meets draw n-1-e of B (the partner lane is the mirror lane of the
+// group, the partner register the mirror register): the A side keeps the minima, the B side the maxima, which leaves
+// two bitonic sequences with every draw of the first at or below every draw of the second; half-cleaners at distance
+// 16 (partner lane L ^ 1, same register; 4-lane level only) and then 8, 4, 2, 1 inside the lane sort each of them.
+// The partner's registers arrive by DPP quad permutes (a VALU operand path, no LDS traffic, no waitcnt); a lane reads
+// its partner's OLD registers because the wave executes the permutes of a register pair before it writes either.
+// 52 VALU per draw for the two levels, no LDS, against 72 VALU + 9 LDS instructions per draw for the same two levels on
+// the merge-path route.  Ties keep their own side (stability is irrelevant: equal draws share one average rank).
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+
+// b where the lane's bit of m is set, else a: one v_cndmask on a mask built on the scalar unit (the compiler's own lowering
+// of a per-lane choice between two compare results goes through 0 / 1 in VGPRs: six more VALU per exchange).
+__device__ __forceinline__ u32 select_by_mask(u32 a, u32 b, unsigned long long m)
+{
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double select_by_mask(double a, double b, unsigned long long m)
+{
+    return __hiloint2double((int)select_by_mask((u32)__double2hiint(a), (u32)__double2hiint(b), m),
+                            (int)select_by_mask((u32)__double2loint(a), (u32)__double2loint(b), m));
+}
+
+// MIN_LANES: the lanes that keep the minimum of an exchange (the others keep the maximum)
+template <int CTRL, bool MIRROR, unsigned long long MIN_LANES>
+__device__ __forceinline__ void lane_pair_stage(double (&k)[16], u32 (&ix)[16])
+{
+    auto exchange = [](double& own, u32& own_i, double o, u32 oi) {
+        const unsigned long long lt = __builtin_amdgcn_ballot_w64(o < own), gt = __builtin_amdgcn_ballot_w64(own < o);
+        const unsigned long long take = (lt & MIN_LANES) | (gt & ~MIN_LANES);
+        own = select_by_mask(own, o, take);
+        own_i = select_by_mask(own_i, oi, take);
+    };
+#pragma unroll
+    for (int r = 0; r < (MIRROR ? 8 : 16); ++r) {
+        const int s = MIRROR ? 15 - r : r;                  // my register r meets the partner's register s
+        const double o_r = dpp_f64<CTRL>(k[s]);
+        const u32 oi_r = dpp_u32<CTRL>(ix[s]);
+        if (MIRROR) {
+            const double o_s = dpp_f64<CTRL>(k[r]);         // ... and my register s the partner's register r
+            const u32 oi_s = dpp_u32<CTRL>(ix[r]);
+            exchange(k[s], ix[s], o_s, oi_s);
+        }
+        exchange(k[r], ix[r], o_r, oi_r);
+    }
+}
+
+__device__ __forceinline__ void lane_bitonic_merge16(double (&k)[16], u32 (&ix)[16])
+{
+#define MCR_CE(a, b)                                                        \
+    {                                                                       \
+        const bool sw = k[b] < k[a];                                        \
+        const double lo = sw ? k[b] : k[a], hi = sw ? k[a] : k[b];          \
+        const u32 ilo = sw ? ix[b] : ix[a], ihi = sw ? ix[a] : ix[b];       \
+        k[a] = lo; k[b] = hi; ix[a] = ilo; ix[b] = ihi;                     \
+    }
+    // half-cleaners at distance 8, 4, 2, 1; every index a literal (a loop-carried index would make hipcc emulate dynamic
+    // register indexing with 16-way select chains)
+    MCR_CE(0, 8) MCR_CE(1, 9) MCR_CE(2, 10) MCR_CE(3, 11) MCR_CE(4, 12) MCR_CE(5, 13) MCR_CE(6, 14) MCR_CE(7, 15)
+    MCR_CE(0, 4) MCR_CE(1, 5) MCR_CE(2, 6) MCR_CE(3, 7) MCR_CE(8, 12) MCR_CE(9, 13) MCR_CE(10, 14) MCR_CE(11, 15)
+    MCR_CE(0, 2) MCR_CE(1, 3) MCR_CE(4, 6) MCR_CE(5, 7) MCR_CE(8, 10) MCR_CE(9, 11) MCR_CE(12, 14) MCR_CE(13, 15)
+    MCR_CE(0, 1) MCR_CE(2, 3) MCR_CE(4, 5) MCR_CE(6, 7) MCR_CE(8, 9) MCR_CE(10, 11) MCR_CE(12, 13) MCR_CE(14, 15)
+#undef MCR_CE
+}
+
+// registers sorted per lane -> runs of 64 draws sorted across every aligned group of 4 lanes
+__device__ __forceinline__ void lane_merge_levels_16_to_64(double (&k)[16], u32 (&ix)[16])
+{
+    constexpr unsigned long long kEvenLanes = 0x5555555555555555ull, kLowPairs = 0x3333333333333333ull;
+    lane_pair_stage<0xB1, true, kEvenLanes>(k, ix);       // quad_perm [1,0,3,2]: 2 x 16 -> 32
+    lane_bitonic_merge16(k, ix);
+    lane_pair_stage<0x1B, true, kLowPairs>(k, ix);        // quad_perm [3,2,1,0]: 2 x 32 -> 64, mirror lane of the quad
+    lane_pair_stage<0xB1, false, kEvenLanes>(k, ix);      // half-cleaner at distance 16
+    lane_bitonic_merge16(k, ix);
+}
+
 // Serial merge of up to VT outputs from LDS runs A = skey[pos16(a0 + .)] (na items) and
 // B = skey[pos16(b0 + .)] (nb items), starting at (ai, bi).  src[i] = LDS slot the output came from.
 // Branch-free.  Which run is exhausted is decided on the POINTERS (two integer compares whose lane masks are combined
@@ -334,6 +414,10 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
 // u32 otherwise.  LDS: skey[T] then sidx[T], nothing else -- the single read "one slot past the last run" of
 // serial_merge lands on sidx[0] (in bounds, value never selected); the reduction scratch reuses skey at the end.
 template <typename IdxT> constexpr size_t sort_lds_bytes(int T) { return (size_t)T * (8 + sizeof(IdxT)); }
+
+#ifndef MCR_TILE_DPP_LEVELS
+#define MCR_TILE_DPP_LEVELS 1
+#endif
 
 template <int NT, int VT, typename IdxT, typename XT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 M,
@@ -375,6 +459,8 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
         ix[i] = (e < count) ? (u32)(base + e) : 0xFFFFFFFFu;
     }
     thread_sort<VT>(k, ix);
+    constexpr bool kLaneLevels = MCR_TILE_DPP_LEVELS && VT == 16;
+    if constexpr (kLaneLevels) lane_merge_levels_16_to_64(k, ix);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VT; ++i) {
@@ -384,7 +470,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
     }
     __syncthreads();
 
-    for (int coop = 2; coop <= NT; coop <<= 1) {
+    for (int coop = kLaneLevels ? 8 : 2; coop <= NT; coop <<= 1) {
         const int first = tid & ~(coop - 1);
         const int run = VT * (coop >> 1);
         const int a0 = first * VT, b0 = a0 + run;
