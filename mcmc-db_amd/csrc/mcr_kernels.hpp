@@ -298,6 +298,10 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 #undef MCR_CE
 }
 
+#ifndef MCR_TILE_DPP_LEVELS
+#define MCR_TILE_DPP_LEVELS 3      // 0: every merge level in LDS; 2 / 3: the first two / three in registers (below)
+#endif
+
 // The first two merge levels of the tile sort (16 -> 32 -> 64 sorted draws) without the LDS: bitonic merges across 2 and 4
 // lanes.  Lane L of a group holds the sorted draws 16 L .. 16 L + 15 of the group's run in its registers.  To merge the
 // ascending runs A and B of a group, draw e of A meets draw n-1-e of B (the partner lane is the mirror lane of the
@@ -376,6 +380,13 @@ __device__ __forceinline__ void lane_merge_levels_16_to_64(double (&k)[16], u32 
     lane_pair_stage<0x1B, true, kLowPairs>(k, ix);        // quad_perm [3,2,1,0]: 2 x 32 -> 64, mirror lane of the quad
     lane_pair_stage<0xB1, false, kEvenLanes>(k, ix);      // half-cleaner at distance 16
     lane_bitonic_merge16(k, ix);
+#if MCR_TILE_DPP_LEVELS >= 3
+    constexpr unsigned long long kLowQuads = 0x0F0F0F0F0F0F0F0Full;
+    lane_pair_stage<0x141, true, kLowQuads>(k, ix);       // row_half_mirror: 2 x 64 -> 128, mirror lane of the group of 8
+    lane_pair_stage<0x4E, false, kLowPairs>(k, ix);       // quad_perm [2,3,0,1]: half-cleaner at distance 32
+    lane_pair_stage<0xB1, false, kEvenLanes>(k, ix);      // half-cleaner at distance 16
+    lane_bitonic_merge16(k, ix);
+#endif
 }
 
 // Serial merge of up to VT outputs from LDS runs A = skey[pos16(a0 + .)] (na items) and
@@ -414,10 +425,6 @@ __device__ __forceinline__ void serial_merge(const double* skey, int a0, int na,
 // u32 otherwise.  LDS: skey[T] then sidx[T], nothing else -- the single read "one slot past the last run" of
 // serial_merge lands on sidx[0] (in bounds, value never selected); the reduction scratch reuses skey at the end.
 template <typename IdxT> constexpr size_t sort_lds_bytes(int T) { return (size_t)T * (8 + sizeof(IdxT)); }
-
-#ifndef MCR_TILE_DPP_LEVELS
-#define MCR_TILE_DPP_LEVELS 1
-#endif
 
 template <int NT, int VT, typename IdxT, typename XT>
 __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 M,
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
         ix[i] = (e < count) ? (u32)(base + e) : 0xFFFFFFFFu;
     }
     thread_sort<VT>(k, ix);
-    constexpr bool kLaneLevels = MCR_TILE_DPP_LEVELS && VT == 16;
+    constexpr bool kLaneLevels = MCR_TILE_DPP_LEVELS >= 2 && VT == 16;
     if constexpr (kLaneLevels) lane_merge_levels_16_to_64(k, ix);
     __syncthreads();
 #pragma unroll
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(NT) void k_tile_sort(const XT* __restrict__ X, i64 
     }
     __syncthreads();
 
-    for (int coop = kLaneLevels ? 8 : 2; coop <= NT; coop <<= 1) {
+    for (int coop = kLaneLevels ? (MCR_TILE_DPP_LEVELS >= 3 ? 16 : 8) : 2; coop <= NT; coop <<= 1) {
         const int first = tid & ~(coop - 1);
         const int run = VT * (coop >> 1);
         const int a0 = first * VT, b0 = a0 + run;
