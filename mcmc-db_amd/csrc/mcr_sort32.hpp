@@ -32,6 +32,68 @@ __device__ __forceinline__ void thread_sort_rec(u64 (&r)[VT])
 #undef MCR_CE
 }
 
+// lane_merge_levels of mcr_kernels.hpp on records: the first three merge levels of the tile sort (16 -> 128 records) as
+// bitonic merges across 2, 4 and 8 lanes over DPP; records are distinct (the position is in the low word), so an
+// exchange is one unsigned compare per side.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v)
+{
+    return ((u64)dpp_u32<CTRL>((u32)(v >> 32)) << 32) | (u64)dpp_u32<CTRL>((u32)v);
+}
+__device__ __forceinline__ u64 select_by_mask(u64 a, u64 b, unsigned long long m)
+{
+    return ((u64)select_by_mask((u32)(a >> 32), (u32)(b >> 32), m) << 32) | (u64)select_by_mask((u32)a, (u32)b, m);
+}
+
+template <int CTRL, bool MIRROR, unsigned long long MIN_LANES>
+__device__ __forceinline__ void lane_pair_stage_rec(u64 (&r)[16])
+{
+    auto exchange = [](u64& own, u64 o) {
+        const unsigned long long lt = __builtin_amdgcn_ballot_w64(o < own), gt = __builtin_amdgcn_ballot_w64(own < o);
+        own = select_by_mask(own, o, (lt & MIN_LANES) | (gt & ~MIN_LANES));
+    };
+#pragma unroll
+    for (int i = 0; i < (MIRROR ? 8 : 16); ++i) {
+        const int s = MIRROR ? 15 - i : i;
+        const u64 o_i = dpp_u64<CTRL>(r[s]);
+        if (MIRROR) {
+            const u64 o_s = dpp_u64<CTRL>(r[i]);
+            exchange(r[s], o_s);
+        }
+        exchange(r[i], o_i);
+    }
+}
+
+__device__ __forceinline__ void lane_bitonic_merge16_rec(u64 (&r)[16])
+{
+#define MCR_CE(a, b)                                         \
+    {                                                        \
+        const bool sw = r[b] < r[a];                         \
+        const u64 lo = sw ? r[b] : r[a], hi = sw ? r[a] : r[b]; \
+        r[a] = lo; r[b] = hi;                                \
+    }
+    MCR_CE(0, 8) MCR_CE(1, 9) MCR_CE(2, 10) MCR_CE(3, 11) MCR_CE(4, 12) MCR_CE(5, 13) MCR_CE(6, 14) MCR_CE(7, 15)
+    MCR_CE(0, 4) MCR_CE(1, 5) MCR_CE(2, 6) MCR_CE(3, 7) MCR_CE(8, 12) MCR_CE(9, 13) MCR_CE(10, 14) MCR_CE(11, 15)
+    MCR_CE(0, 2) MCR_CE(1, 3) MCR_CE(4, 6) MCR_CE(5, 7) MCR_CE(8, 10) MCR_CE(9, 11) MCR_CE(12, 14) MCR_CE(13, 15)
+    MCR_CE(0, 1) MCR_CE(2, 3) MCR_CE(4, 5) MCR_CE(6, 7) MCR_CE(8, 9) MCR_CE(10, 11) MCR_CE(12, 13) MCR_CE(14, 15)
+#undef MCR_CE
+}
+
+__device__ __forceinline__ void lane_merge_levels_rec(u64 (&r)[16])
+{
+    constexpr unsigned long long kEvenLanes = 0x5555555555555555ull, kLowPairs = 0x3333333333333333ull,
+                                 kLowQuads = 0x0F0F0F0F0F0F0F0Full;
+    lane_pair_stage_rec<0xB1, true, kEvenLanes>(r);
+    lane_bitonic_merge16_rec(r);
+    lane_pair_stage_rec<0x1B, true, kLowPairs>(r);
+    lane_pair_stage_rec<0xB1, false, kEvenLanes>(r);
+    lane_bitonic_merge16_rec(r);
+    lane_pair_stage_rec<0x141, true, kLowQuads>(r);
+    lane_pair_stage_rec<0x4E, false, kLowPairs>(r);
+    lane_pair_stage_rec<0xB1, false, kEvenLanes>(r);
+    lane_bitonic_merge16_rec(r);
+}
+
 // serial_merge of mcr_kernels.hpp on records: the record IS the payload, so there is nothing to gather afterwards.
 // LIM > 0: slot indices are clamped to LIM (k_tile_sort32 declares exactly T slots so that five tiles fit a CU, and
 // the unconditional read one past the last run must not leave them).
@@ -99,12 +161,14 @@ __global__ __launch_bounds__(NT) void k_tile_sort32(const float* __restrict__ X,
 #pragma unroll
     for (int i = 0; i < VT; ++i) r[i] = srec[pos16(tid * VT + i)];
     thread_sort_rec<VT>(r);
+    constexpr bool kLaneLevels = MCR_TILE_DPP_LEVELS >= 3 && VT == 16;
+    if constexpr (kLaneLevels) lane_merge_levels_rec(r);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < VT; ++i) srec[pos16(tid * VT + i)] = r[i];
     __syncthreads();
 
-    for (int coop = 2; coop <= NT; coop <<= 1) {
+    for (int coop = kLaneLevels ? 16 : 2; coop <= NT; coop <<= 1) {
         const int first = tid & ~(coop - 1);
         const int run = VT * (coop >> 1);
         const int a0 = first * VT, b0 = a0 + run;
