@@ -311,7 +311,9 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 // The partner's registers arrive by DPP quad permutes (a VALU operand path, no LDS traffic, no waitcnt); a lane reads
 // its partner's OLD registers because the wave executes the permutes of a register pair before it writes either.
 // 52 VALU per draw for the two levels, no LDS, against 72 VALU + 9 LDS instructions per draw for the same two levels on
-// the merge-path route.  Ties keep their own side (stability is irrelevant: equal draws share one average rank).
+// the merge-path route.  A third level (8 lanes: row_half_mirror, then distances 32 and 16) costs the VALU of its LDS
+// form and still wins for the LDS instructions and the barrier pair it saves; a fourth (16 lanes: lane ^ 4 takes two
+// DPP movs per word) measured slower than its LDS form (tile sort 396 -> 408 us on 1000 parameters).  Ties keep their own side (stability is irrelevant: equal draws share one average rank).
 template <int CTRL>
 __device__ __forceinline__ u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
 
