@@ -364,12 +364,9 @@ __device__ __forceinline__ void lane_bitonic_merge16(double (&k)[16], u32 (&ix)[
         const u32 ilo = sw ? ix[b] : ix[a], ihi = sw ? ix[a] : ix[b];       \
         k[a] = lo; k[b] = hi; ix[a] = ilo; ix[b] = ihi;                     \
     }
-    // half-cleaners at distance 8, 4, 2, 1; every index a literal (a loop-carried index would make hipcc emulate dynamic
-    // register indexing with 16-way select chains)
-    MCR_CE(0, 8) MCR_CE(1, 9) MCR_CE(2, 10) MCR_CE(3, 11) MCR_CE(4, 12) MCR_CE(5, 13) MCR_CE(6, 14) MCR_CE(7, 15)
-    MCR_CE(0, 4) MCR_CE(1, 5) MCR_CE(2, 6) MCR_CE(3, 7) MCR_CE(8, 12) MCR_CE(9, 13) MCR_CE(10, 14) MCR_CE(11, 15)
-    MCR_CE(0, 2) MCR_CE(1, 3) MCR_CE(4, 6) MCR_CE(5, 7) MCR_CE(8, 10) MCR_CE(9, 11) MCR_CE(12, 14) MCR_CE(13, 15)
-    MCR_CE(0, 1) MCR_CE(2, 3) MCR_CE(4, 5) MCR_CE(6, 7) MCR_CE(8, 9) MCR_CE(10, 11) MCR_CE(12, 13) MCR_CE(14, 15)
+    // half-cleaners at distance 8, 4, 2, 1 (mcr_sortnet.h); every index a literal (a loop-carried index would make hipcc
+    // emulate dynamic register indexing with 16-way select chains)
+    MCR_BITONIC16(MCR_CE)
 #undef MCR_CE
 }
 

@@ -72,10 +72,7 @@ __device__ __forceinline__ void lane_bitonic_merge16_rec(u64 (&r)[16])
         const u64 lo = sw ? r[b] : r[a], hi = sw ? r[a] : r[b]; \
         r[a] = lo; r[b] = hi;                                \
     }
-    MCR_CE(0, 8) MCR_CE(1, 9) MCR_CE(2, 10) MCR_CE(3, 11) MCR_CE(4, 12) MCR_CE(5, 13) MCR_CE(6, 14) MCR_CE(7, 15)
-    MCR_CE(0, 4) MCR_CE(1, 5) MCR_CE(2, 6) MCR_CE(3, 7) MCR_CE(8, 12) MCR_CE(9, 13) MCR_CE(10, 14) MCR_CE(11, 15)
-    MCR_CE(0, 2) MCR_CE(1, 3) MCR_CE(4, 6) MCR_CE(5, 7) MCR_CE(8, 10) MCR_CE(9, 11) MCR_CE(12, 14) MCR_CE(13, 15)
-    MCR_CE(0, 1) MCR_CE(2, 3) MCR_CE(4, 5) MCR_CE(6, 7) MCR_CE(8, 9) MCR_CE(10, 11) MCR_CE(12, 13) MCR_CE(14, 15)
+    MCR_BITONIC16(MCR_CE)
 #undef MCR_CE
 }
 

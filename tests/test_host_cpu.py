@@ -250,6 +250,67 @@ int main(void) {
     assert out == ["60", "0", "19", "0"]
 
 
+def test_register_merge_levels_merge_every_pair_of_sorted_01_runs(tmp_path):
+    """The tile sort's merge levels in registers (csrc/mcr_kernels.hpp lane_merge_levels_16_to_64 and its third level):
+    a group of 2 / 4 / 8 lanes with 16 registers each holds two sorted runs; the mirror exchange with the partner lane
+    (lane ^ 1, mirror lane of the quad, mirror lane of the group of 8; mirror register), the half-cleaners across lanes
+    (lane ^ 2, lane ^ 1; same register) and the 16-input bitonic merge of mcr_sortnet.h inside each lane must leave the
+    group sorted.  0-1 principle for merging networks: every pair of sorted 0-1 runs."""
+    import subprocess
+    src = tmp_path / "levels.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "mcr_sortnet.h"
+#define X(a, b) {a, b},
+static const int bit16[][2] = { MCR_BITONIC16(X) };
+static int v[8][16];
+/* one exchange stage as the kernel does it: every lane reads the partner's OLD registers */
+static void stage(int lanes, int xor_or_mirror, int mirror_regs, int min_mask) {
+    int o[8][16];
+    memcpy(o, v, sizeof(o));
+    for (int l = 0; l < lanes; ++l) {
+        const int partner = xor_or_mirror < 0 ? (l & ~(-xor_or_mirror - 1)) + ((-xor_or_mirror - 1) - (l & (-xor_or_mirror - 1))) : l ^ xor_or_mirror;
+        const int keep_min = (l & min_mask) == 0;
+        for (int r = 0; r < 16; ++r) {
+            const int other = o[partner][mirror_regs ? 15 - r : r], own = o[l][r];
+            v[l][r] = keep_min ? (other < own ? other : own) : (own < other ? other : own);
+        }
+    }
+}
+static void local(int lanes) {
+    const int n = (int)(sizeof(bit16) / sizeof(bit16[0]));
+    for (int l = 0; l < lanes; ++l)
+        for (int c = 0; c < n; ++c) { const int a = bit16[c][0], b = bit16[c][1];
+            if (v[l][b] < v[l][a]) { const int t = v[l][a]; v[l][a] = v[l][b]; v[l][b] = t; } }
+}
+static long level(int lanes) {   /* lanes = 2, 4, 8: two sorted runs of 8 * lanes inputs each */
+    const int half = 8 * lanes;
+    long bad = 0;
+    for (int za = 0; za <= half; ++za)
+        for (int zb = 0; zb <= half; ++zb) {       /* run A: za zeros then ones; run B: zb zeros then ones */
+            for (int e = 0; e < half; ++e) { v[e / 16][e % 16] = e >= za; v[lanes / 2 + e / 16][e % 16] = e >= zb; }
+            stage(lanes, -lanes, 1, lanes / 2);            /* mirror lane of the group, mirror register */
+            for (int d = lanes / 4; d >= 1; d /= 2) stage(lanes, d, 0, d);      /* half-cleaners across lanes */
+            local(lanes);
+            int prev = 0, ones = 0;
+            for (int e = 0; e < 2 * half; ++e) { const int x = v[e / 16][e % 16]; if (x < prev) { ++bad; break; } prev = x; ones += x; }
+            if (ones != 2 * half - za - zb) ++bad;
+        }
+    return bad;
+}
+int main(void) {
+    const long b2 = level(2), b4 = level(4), b8 = level(8);
+    printf("%ld %ld %ld\n", b2, b4, b8);
+    return b2 != 0 || b4 != 0 || b8 != 0;
+}
+''')
+    exe = tmp_path / "levels"
+    subprocess.run(["gcc", "-O2", "-I", str(ROOT / "mcmc-db_amd" / "csrc"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["0", "0", "0"]
+
+
 def test_store_layout_and_precedence(tmp_path):
     import pyarrow as pa
     import pyarrow.parquet as pq
