@@ -79,6 +79,36 @@ __device__ __forceinline__ double wave_excl_scan(double v, double& total)
     return incl - v;
 }
 
+// Integer scans over the 64 lanes of a wave on DPP (all lanes active).  OLD = the identity of the operation, which lanes
+// without a source keep.
+template <int CTRL, int ROW_MASK, int OLD>
+__device__ __forceinline__ int dpp_i32_or(int v) { return __builtin_amdgcn_update_dpp(OLD, v, CTRL, ROW_MASK, 0xf, false); }
+
+// inclusive prefix maximum (values >= -1); `excl` <- the prefix maximum of the lanes before this one (-1 in lane 0)
+__device__ __forceinline__ int wave_prefix_max(int v, int& excl)
+{
+    v = max(v, dpp_i32_or<0x111, 0xf, -1>(v)); v = max(v, dpp_i32_or<0x112, 0xf, -1>(v));
+    v = max(v, dpp_i32_or<0x114, 0xf, -1>(v)); v = max(v, dpp_i32_or<0x118, 0xf, -1>(v));
+    v = max(v, dpp_i32_or<0x142, 0xa, -1>(v)); v = max(v, dpp_i32_or<0x143, 0xc, -1>(v));
+    excl = dpp_i32_or<0x138, 0xf, -1>(v);                       // wave_shr:1
+    return v;
+}
+// inclusive suffix minimum; `excl` <- the suffix minimum of the lanes after this one (INT_MAX in lane 63).  There is no
+// row broadcast towards lower lanes: the rows' minima (their lanes 0) come back as scalars.
+__device__ __forceinline__ int wave_suffix_min(int v, int& excl)
+{
+    constexpr int kMax = 0x7fffffff;
+    v = min(v, dpp_i32_or<0x101, 0xf, kMax>(v)); v = min(v, dpp_i32_or<0x102, 0xf, kMax>(v));
+    v = min(v, dpp_i32_or<0x104, 0xf, kMax>(v)); v = min(v, dpp_i32_or<0x108, 0xf, kMax>(v));      // row_shl 1, 2, 4, 8
+    const int r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int row = (threadIdx.x & 63) >> 4;
+    const int m23 = min(r2, r3), m123 = min(r1, m23);
+    const int above = (row == 0) ? m123 : ((row == 1) ? m23 : ((row == 2) ? r3 : kMax));
+    v = min(v, above);
+    excl = dpp_i32_or<0x130, 0xf, kMax>(v);                     // wave_shl:1
+    return v;
+}
+
 // Deterministic block sum (fixed association order): wave shuffle tree, then waves in index order.
 // `red` is LDS scratch of NT/64 doubles.  Every thread gets the result.
 template <int NT>

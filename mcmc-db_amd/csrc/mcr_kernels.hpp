@@ -544,14 +544,10 @@ __device__ __forceinline__ void block_tie_runs(KF key_at, int total, int* wsh, i
         rs[i] = cur;
         prev = kv;
     }
-    // exclusive max-scan of `cur` (last head at or before the end of my chunk) over threads
-    int incl = cur;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, kWave); if (lane >= o) incl = max(incl, v); }
-    // exclusive reverse min-scan of `first`
-    int rinc = first;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(rinc, o, kWave); if (lane + o < 64) rinc = min(rinc, v); }
+    // max-scan of `cur` (last head at or before the end of my chunk) and reverse min-scan of `first` over the lanes (DPP)
+    int exL, exR;
+    const int incl = wave_prefix_max(cur, exL);
+    const int rinc = wave_suffix_min(first, exR);
     __syncthreads();
     if (lane == 63) wsh[w] = incl;
     if (lane == 0) wsh[NW + w] = rinc;
@@ -562,9 +558,8 @@ __device__ __forceinline__ void block_tie_runs(KF key_at, int total, int* wsh, i
         if (ww < w) carryL = max(carryL, wsh[ww]);
         if (ww > w) carryR = min(carryR, wsh[NW + ww]);
     }
-    const int exL = __shfl_up(incl, 1, kWave), exR = __shfl_down(rinc, 1, kWave);
-    if (lane > 0) carryL = max(carryL, exL);
-    if (lane < 63) carryR = min(carryR, exR);
+    carryL = max(carryL, exL);          // (the identities in lanes 0 / 63)
+    carryR = min(carryR, exR);
     if (carryR > total) carryR = total;
     int nxt = carryR;
 #pragma unroll
