@@ -79,6 +79,19 @@ __device__ __forceinline__ double wave_excl_scan(double v, double& total)
     return incl - v;
 }
 
+// The value lane j (0..15) of the caller's row of 16 lanes holds: DPP row_newbcast (gfx90a and later).  The control is an
+// immediate, so j must be a constant once the calling loop is unrolled.
+__device__ __forceinline__ int row_lane(int v, int j)
+{
+#define MCR_RL(J) case J: return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
+    switch (j & 15) {
+        MCR_RL(0) MCR_RL(1) MCR_RL(2) MCR_RL(3) MCR_RL(4) MCR_RL(5) MCR_RL(6) MCR_RL(7)
+        MCR_RL(8) MCR_RL(9) MCR_RL(10) MCR_RL(11) MCR_RL(12) MCR_RL(13) MCR_RL(14)
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);
+    }
+#undef MCR_RL
+}
+
 // Integer scans over the 64 lanes of a wave on DPP (all lanes active).  OLD = the identity of the operation, which lanes
 // without a source keep.
 template <int CTRL, int ROW_MASK, int OLD>

@@ -913,14 +913,15 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     const i64 obase = boff[p * (B + 1) + b];
     if (padded > T - 64 || total < 0 || total > padded || obase + total > M) return;   // never with a valid partition
     // gather pieces (+inf pads).  Slot e = j * NT + tid: a wave's j-th load covers 64 consecutive slots = four 16-slot
-    // chunks, and a chunk never straddles pieces (they are padded to 16).  Lane l < 4 VT looks up the piece of chunk
-    // (l / 4, l % 4) ONCE; the element loop fetches {source offset, live length} from that lane and issues all VT
-    // loads back to back (one piece search per 16 slots instead of one per slot, no load waits for the previous one).
+    // chunks, one per DPP row of 16 lanes, and a chunk never straddles pieces (they are padded to 16).  Lane j of row q
+    // looks up the piece of the row's j-th chunk ONCE; the element loop takes {source offset, live length} from that lane
+    // with a row broadcast and issues all VT loads back to back (one piece search per 16 slots instead of one per slot,
+    // no load waits for the previous one).
     {
         const int lane = tid & 63, wv = tid >> 6;
         u32 my_g = 0; int my_n = 0;
-        if (lane < 4 * VT) {
-            const int e0 = (lane >> 2) * NT + 64 * wv + 16 * (lane & 3);
+        if ((lane & 15) < VT) {
+            const int e0 = (lane & 15) * NT + 64 * wv + 16 * (lane >> 4);
             if (e0 < padded) {
                 int t = 0;   // last piece whose padded start is <= e0 (starts are non-decreasing)
 #pragma unroll
@@ -934,9 +935,9 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
         double gv[VT]; IdxT gi[VT];
 #pragma unroll
         for (int j = 0; j < VT; ++j) {
-            const int from = 4 * j + (lane >> 4), within = lane & 15;
-            const u32 g0 = (u32)__shfl((int)my_g, from);
-            const int n = __shfl(my_n, from);
+            const int within = lane & 15;
+            const u32 g0 = (u32)row_lane((int)my_g, j);      // lane j of my row of 16 looked the chunk up
+            const int n = row_lane(my_n, j);
             const bool live = within < n;
             const i64 g = live ? (i64)(g0 + (u32)within) : 0;     // dead slots read element 0 (always there) and drop it
             const double v = kp[g]; const IdxT id = ip[g];

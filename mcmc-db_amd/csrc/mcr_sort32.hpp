@@ -297,8 +297,8 @@ __global__ __launch_bounds__(NT) void k_bucket_merge32(const u64* __restrict__ r
     {   // gather: one piece search per 16-slot chunk, all VT loads in flight together (see k_bucket_merge)
         const int lane = tid & 63, wv = tid >> 6;
         u32 my_g = 0; int my_n = 0;
-        if (lane < 4 * VT) {
-            const int e0 = (lane >> 2) * NT + 64 * wv + 16 * (lane & 3);
+        if ((lane & 15) < VT) {
+            const int e0 = (lane & 15) * NT + 64 * wv + 16 * (lane >> 4);
             if (e0 < padded) {
                 int t = 0;
 #pragma unroll
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(NT) void k_bucket_merge32(const u64* __restrict__ r
         u64 gr[VT];
 #pragma unroll
         for (int j = 0; j < VT; ++j) {
-            const int from = 4 * j + (lane >> 4), within = lane & 15;
-            const u32 g0 = (u32)__shfl((int)my_g, from);
-            const int n = __shfl(my_n, from);
+            const int within = lane & 15;
+            const u32 g0 = (u32)row_lane((int)my_g, j);      // lane j of my row of 16 looked the chunk up
+            const int n = row_lane(my_n, j);
             const bool live = within < n;
             const u64 r = rp[live ? (i64)(g0 + (u32)within) : 0];
             gr[j] = live ? r : kRecPad;
