@@ -38,7 +38,10 @@
 namespace mcr {
 
 constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (1024 for chains of <= 1024 draws)
-constexpr int kLag1 = 64;       // tier 1: lags 0 .. 63 (a multiple of 8, at most 64: one lag per lane in k_diag_combine)
+#ifndef MCR_LAG1
+#define MCR_LAG1 64
+#endif
+constexpr int kLag1 = MCR_LAG1; // tier 1: lags 0 .. kLag1-1 (32 or 64: one lag per lane in k_diag_combine)
 constexpr int kSegRec = kLag1 + 8;   // doubles per tier-1 record: the lag products + 7 scalars
 constexpr int kMoreBlocks = 3;  // tier 2: lags 64 .. 64 + 64*3 - 1 = 255
 constexpr int kLag2 = kLag1 + 64 * kMoreBlocks;   // first lag of tier 3
@@ -122,21 +125,25 @@ __device__ __forceinline__ void seg_reduce(double (&acc)[LPL], double* tot, doub
 // seg_reduce for the 8 x 8 tile with the cross-lane part on DPP and the LDS: the two phases that share a DPP row are
 // added with one row rotation, the four rows of every wave go to `scr` (NT / 64 * 4 * 64 doubles; it may alias the
 // staged segment, which is dead by then) and 64 threads add them.  No ds_bpermute.  All NT threads must call it.
-template <int NT>
+template <int NT, int LG = 8>
 __device__ __forceinline__ void seg_reduce_rows(double (&acc)[8], double* tot, double* scr)
 {
     constexpr int NW = NT / kWave;
+    static_assert(LG == 8 || LG == 4, "8 or 4 lag groups of 8 lags");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane & 7, row = lane >> 4;
+    const int g = lane & (LG - 1), row = lane >> 4;
 #pragma unroll
-    for (int li = 0; li < 8; ++li) acc[li] += dpp_f64<kDppRor8>(acc[li]);
+    for (int li = 0; li < 8; ++li) {
+        if (LG == 4) acc[li] += dpp_f64<kDppRor4>(acc[li]);       // four phases share a row: l, l + 4, l + 8, l + 12
+        acc[li] += dpp_f64<kDppRor8>(acc[li]);
+    }
     __syncthreads();  // scr / tot may still be in use
-    if ((lane & 8) == 0) {
+    if ((lane & 15) < LG) {
 #pragma unroll
         for (int li = 0; li < 8; ++li) scr[(w * 4 + row) * 64 + g * 8 + li] = acc[li];
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < LG * 8) {
         double t = 0.0;
 #pragma unroll
         for (int r = 0; r < NW * 4; ++r) t += scr[r * 64 + tid];
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
 {
     constexpr int NW = NT / kWave;
     static_assert(SEG % 128 == 0, "spans of the widest tile are 128 draws");
-    static_assert(kLag1 == 64, "lag blocks are 64 wide");
+    static_assert(kLag1 == 64 || kLag1 == 32, "tier 1 is one or half a lag block");
     constexpr int WIN = FIRST ? SEG + 80 : SEG + 64 * kMoreBlocks + 80;     // staged window (draws)
     constexpr int LX = WIN / 8 * 10;                                         // its swizzled length
     constexpr int NLD = (WIN + NT - 1) / NT;
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         double acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-        seg_accumulate<NT, 8, 8>(sx, sx, seglen, acc);
-        seg_reduce_rows<NT>(acc, tot, sx);          // the staged window is dead after the barrier inside
+        seg_accumulate<NT, kLag1 / 8, 8>(sx, sx, seglen, acc);
+        seg_reduce_rows<NT, kLag1 / 8>(acc, tot, sx);          // the staged window is dead after the barrier inside
         if (tid < kLag1) r[tid] = tot[tid];
     } else {
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * (64 * kMoreBlocks);
