@@ -39,16 +39,18 @@ __device__ __forceinline__ double row_sum(double v)
     v += dpp_f64<kDppXor1>(v); v += dpp_f64<kDppXor2>(v); v += dpp_f64<kDppRor4>(v); v += dpp_f64<kDppRor8>(v);
     return v;
 }
-__device__ __forceinline__ double row_min(double v)
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 row_min_u32(u32 v)
 {
-    v = fmin(v, dpp_f64<kDppXor1>(v)); v = fmin(v, dpp_f64<kDppXor2>(v));
-    v = fmin(v, dpp_f64<kDppRor4>(v)); v = fmin(v, dpp_f64<kDppRor8>(v));
+    v = min(v, dpp_u32<kDppXor1>(v)); v = min(v, dpp_u32<kDppXor2>(v));
+    v = min(v, dpp_u32<kDppRor4>(v)); v = min(v, dpp_u32<kDppRor8>(v));
     return v;
 }
-__device__ __forceinline__ double row_max(double v)
+__device__ __forceinline__ u32 row_max_u32(u32 v)
 {
-    v = fmax(v, dpp_f64<kDppXor1>(v)); v = fmax(v, dpp_f64<kDppXor2>(v));
-    v = fmax(v, dpp_f64<kDppRor4>(v)); v = fmax(v, dpp_f64<kDppRor8>(v));
+    v = max(v, dpp_u32<kDppXor1>(v)); v = max(v, dpp_u32<kDppXor2>(v));
+    v = max(v, dpp_u32<kDppRor4>(v)); v = max(v, dpp_u32<kDppRor8>(v));
     return v;
 }
 // All 64 lanes must be active.  Every lane gets the same value (the four row totals of lanes 0, 16, 32, 48).

@@ -198,12 +198,17 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         const int a0 = (hc > 0) ? clip(rel(0)) : 0, a1 = (hc > 0) ? clip(rel(nh)) : 0;             // first half
         const int b0 = (hc > 0) ? clip(rel(hc)) : 0, b1 = (hc > 0) ? clip(rel(hc + nh)) : 0;        // second half
         double S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0;
-        double vmin = INFINITY, vmax = -INFINITY;
+        // min / max only tell a constant chain (min == max) from the others, and z = ztab[code] is strictly monotone:
+        // they are taken on the integer codes (full-rate v_min_u32 / v_max_u32; the f64 pair is not, and needs its operands
+        // canonicalised) and stored as doubles, which hold a u32 exactly
+        u32 cmin = 0xFFFFFFFFu, cmax = 0u;
         double v[NLD];
+        u32 cd[NLD];
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int j = u * NT + tid;
-            v[u] = (j < r_load) ? zdec(ztab, zc[s0 + j], M) : 0.0;
+            cd[u] = (j < r_load) ? zc[s0 + j] : 0u;
+            v[u] = (j < r_load) ? zdec(ztab, cd[u], M) : 0.0;
         }
         // The three windows are ranges of j and a wave's 64 slots are consecutive: a wave that lies wholly inside (or
         // outside) a window -- all but a handful -- decides that with scalar compares and adds without per-lane masks.
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         for (int u = 0; u < NLD; ++u) {
             const int jw = u * NT + jw0, j = u * NT + tid;
             const double x = v[u];
-            MCR_IN_WINDOW(0, own_n, S += x; vmin = fmin(vmin, x); vmax = fmax(vmax, x);)
+            MCR_IN_WINDOW(0, own_n, S += x; cmin = min(cmin, cd[u]); cmax = max(cmax, cd[u]);)
             MCR_IN_WINDOW(a0, a1, S0 += x; Q0 = fma(x, x, Q0);)
             MCR_IN_WINDOW(b0, b1, S1 += x; Q1 = fma(x, x, Q1);)
             if (j < WIN) sx[pos8(j)] = (j < r_n) ? x : 0.0;
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         // The five sums and min / max: DPP inside the rows of 16 lanes, the 4 NW row results through the LDS, seven
         // lanes finish (one barrier; no cross-row shuffles).
         S = row_sum(S); S0 = row_sum(S0); Q0 = row_sum(Q0); S1 = row_sum(S1); Q1 = row_sum(Q1);
-        vmin = row_min(vmin); vmax = row_max(vmax);
+        cmin = row_min_u32(cmin); cmax = row_max_u32(cmax);
         if ((tid & 15) == 0) {
             double* q = wred + (tid >> 4) * 8;
-            q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = vmin; q[6] = vmax;
+            q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = (double)cmin; q[6] = (double)cmax;
         }
         __syncthreads();
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;

@@ -314,9 +314,6 @@ __device__ __forceinline__ void thread_sort(double (&k)[VT], u32 (&ix)[VT])
 // the merge-path route.  A third level (8 lanes: row_half_mirror, then distances 32 and 16) costs the VALU of its LDS
 // form and still wins for the LDS instructions and the barrier pair it saves; a fourth (16 lanes: lane ^ 4 takes two
 // DPP movs per word) measured slower than its LDS form (tile sort 396 -> 408 us on 1000 parameters).  Ties keep their own side (stability is irrelevant: equal draws share one average rank).
-template <int CTRL>
-__device__ __forceinline__ u32 dpp_u32(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
-
 // b where the lane's bit of m is set, else a: one v_cndmask on a mask built on the scalar unit (the compiler's own lowering
 // of a per-lane choice between two compare results goes through 0 / 1 in VGPRs: six more VALU per exchange).
 __device__ __forceinline__ u32 select_by_mask(u32 a, u32 b, unsigned long long m)
