@@ -144,6 +144,12 @@ def load_library():
                 raise HipUnavailableError(
                     f"{path} not found: build it with `python mcmc-db_amd/build.py` "
                     "(there is no CPU fallback)")
+            # Multi-process RCCL (N > 1 ranks, one per GPU) exchanges device buffers between processes over IPC handles.  The
+            # host driver of this platform supports only the dmabuf form; with the HSA runtime's legacy IPC mode (its
+            # default) `hipIpcGetMemHandle` fails with "invalid argument" inside ncclCommInitRank.  The runtime reads the
+            # variable when it initialises, i.e. at the first HIP call, so it is set here, before the library is mapped;
+            # a value the launcher exported wins.  It changes nothing for a single process.
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             try:
                 L = C.CDLL(str(path))
             except OSError as exc:

@@ -6,7 +6,7 @@ cut into contiguous parameter blocks (`param_block`), and a single 
 summary records (16 doubles = 128 bytes) at the end.  The collective is `ncclAllGather` inside libmcmcref_hip
 (`mcr_comm_all_gather`, RCCL over xGMI): no torch, no MPI.  Ranks find each other through the environment a
 `torch.distributed.run` / torchrun launch provides (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT): rank 0
-publishes the 128-byte ncclUniqueId in a file keyed on those, the others read it.
+hands the 128-byte ncclUniqueId to the others through files keyed on those (`exchange_unique_id`).
 
 The gather is latency-bound (packaged corpus: 460 records = 59 KB; a 10 000-parameter model: 1.3 MB), so xGMI link
 bandwidth is irrelevant to it.  What to expect from N GPUs: independent models of C1 size scale weakly (each rank
@@ -60,14 +60,122 @@ def param_block(P: int, world: int, rank: int) -> tuple[int, int]:
 
 
 # ---- the communicator ------------------------------------------------------------------------------------------
+# Rendezvous of the ranks of ONE launch, torch-free: rank 0 creates the 128-byte ncclUniqueId and hands it to the other
+# ranks through small files in a directory every rank of the launch can see (the local temp dir for a single node,
+# MCR_COMM_DIR on a shared file system otherwise).
+#
+# Which launch a file belongs to (`comm_key`):
+#   * MCR_COMM_KEY, when exported, is the key -- any launcher (srun, mpirun, a shell loop) can provide one;
+#   * otherwise MASTER_ADDR / MASTER_PORT / world size / TORCHELASTIC_RESTART_COUNT, plus TORCHELASTIC_RUN_ID when the
+#     launcher was given a real run id (`torchrun --rdzv-id X`), plus -- only when the run id is absent or torchrun's
+#     default "none" -- the pid of the launcher (os.getppid()): `python -m torch.distributed.run` / torchrun start the
+#     ranks as direct children of one agent process, so they agree on it.  A launcher that puts a shell between itself
+#     and each rank must export MCR_COMM_KEY (or a run id); the TimeoutError of a rank that never finds rank 0 prints
+#     the resolved path and the key parts, so a disagreement is visible at once.
+#
+# The hand-over itself (`exchange_unique_id`) cannot pick up a file a crashed earlier launch left under the same key:
+# every rank r > 0 publishes a fresh random nonce (`<base>.hello.<r>`), rank 0 publishes `id || nonce_1 .. nonce_{w-1}`
+# (`<base>.id`, atomic rename, republished when a hello changes under it), rank r accepts an id file only if it carries
+# ITS nonce and then acknowledges with `<base>.ack.<r>`; rank 0 returns once every ack matches and removes the files.
+COMM_NONCE_BYTES = 16
+
+
+def comm_key(world: int) -> tuple[str, list[str]]:
+    """(key, parts) of this launch; see the block comment above for the resolution order."""
+    explicit = os.environ.get("MCR_COMM_KEY")
+    if explicit:
+        parts = ["MCR_COMM_KEY=" + explicit]
+        key = explicit
+    else:
+        run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+        parts = ["MASTER_ADDR=" + os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                 "MASTER_PORT=" + os.environ.get("MASTER_PORT", "0"), f"world={world}",
+                 "TORCHELASTIC_RESTART_COUNT=" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")]
+        if run_id and run_id != "none":
+            parts.append("TORCHELASTIC_RUN_ID=" + run_id)
+        else:
+            parts.append(f"launcher_pid={os.getppid()}")
+        key = "_".join(x.split("=", 1)[1] for x in parts)
+    return "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in key), parts
+
+
 def _id_file(world: int) -> Path:
-    """Where rank 0 publishes the ncclUniqueId of this launch: keyed on MASTER_ADDR / MASTER_PORT (+ the launcher's
-    pid and restart count, so that consecutive launches on one port never read each other's id)."""
+    """Base path of the rendezvous files of this launch (`<base>.id`, `<base>.hello.<r>`, `<base>.ack.<r>`)."""
     d = Path(os.environ.get("MCR_COMM_DIR", tempfile.gettempdir()))
-    key = "_".join([os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), str(world),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
-                    os.environ.get("MCR_COMM_KEY", str(os.getppid()))])
-    return d / f"mcr_rccl_id_{key.replace('/', '-').replace(':', '-')}"
+    return d / f"mcr_rccl_id_{comm_key(world)[0]}"
+
+
+def _publish(path: Path, payload: bytes) -> None:
+    tmp = path.with_name(path.name + f".{os.getpid()}.tmp")
+    tmp.write_bytes(payload)
+    os.replace(tmp, path)                               # atomic: a reader sees the whole payload or no file
+
+
+def _read(path: Path) -> bytes:
+    try:
+        return path.read_bytes()
+    except (FileNotFoundError, PermissionError):
+        return b""
+
+
+def exchange_unique_id(rank: int, world: int, make_id, *, timeout: float = 300.0, base: Path | None = None,
+                       poll: float = 0.005) -> bytes:
+    """Rank 0 calls `make_id()` (-> COMM_ID_BYTES bytes) and every rank returns those bytes.  File protocol described
+    above; raises TimeoutError (naming the path and the key parts) when the other side never shows up."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad world / rank")
+    if world == 1:
+        return bytes(make_id())
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    if base is None and lws and int(lws) != world and not os.environ.get("MCR_COMM_DIR"):
+        raise RuntimeError(f"multi-node launch (LOCAL_WORLD_SIZE={lws}, WORLD_SIZE={world}): export MCR_COMM_DIR = a "
+                           "directory every node sees; the default temp dir is node-local")
+    base = _id_file(world) if base is None else Path(base)
+    idp = base.with_name(base.name + ".id")
+    hello = lambda r: base.with_name(base.name + f".hello.{r}")       # noqa: E731
+    ack = lambda r: base.with_name(base.name + f".ack.{r}")           # noqa: E731
+    t0 = time.monotonic()
+
+    def expired(what: str):
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}/{world}: {what} after {timeout:.0f} s; rendezvous files {base}.* "
+                               f"(key parts: {', '.join(comm_key(world)[1])}).  Ranks behind different parent processes "
+                               "need MCR_COMM_KEY (or torchrun --rdzv-id) to agree on the key")
+        time.sleep(poll)
+
+    if rank == 0:
+        uid = bytes(make_id())
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError(f"make_id() returned {len(uid)} bytes, want {COMM_ID_BYTES}")
+        published: list[bytes] | None = None
+        try:
+            while True:
+                nonces = [_read(hello(r)) for r in range(1, world)]
+                if all(len(x) == COMM_NONCE_BYTES for x in nonces):
+                    if nonces != published:             # first time, or a rank replaced a stale hello by its own
+                        _publish(idp, uid + b"".join(nonces))
+                        published = nonces
+                    if all(_read(ack(r)) == nonces[r - 1] for r in range(1, world)):
+                        return uid
+                expired("not every rank said hello / acknowledged the id")
+        finally:
+            for f in [idp] + [hello(r) for r in range(1, world)] + [ack(r) for r in range(1, world)]:
+                try:
+                    f.unlink()
+                except FileNotFoundError:
+                    pass
+    nonce = os.urandom(COMM_NONCE_BYTES)
+    _publish(hello(rank), nonce)
+    want = COMM_ID_BYTES + COMM_NONCE_BYTES * (world - 1)
+    o = COMM_ID_BYTES + COMM_NONCE_BYTES * (rank - 1)
+    while True:
+        raw = _read(idp)
+        if len(raw) == want and raw[o:o + COMM_NONCE_BYTES] == nonce:
+            _publish(ack(rank), nonce)
+            return raw[:COMM_ID_BYTES]
+        if not hello(rank).exists():                   # a crashed launch's rank 0 clean-up may have taken it: say hello again
+            _publish(hello(rank), nonce)
+        expired("no RCCL id carrying this rank's nonce from rank 0")
 
 
 class Communicator:
@@ -79,37 +187,18 @@ class Communicator:
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         L = ctx.lib
-        uid = (C.c_ubyte * COMM_ID_BYTES)()
-        path = _id_file(self.world)
-        if self.rank == 0:
+
+        def make_id() -> bytes:
+            uid = (C.c_ubyte * COMM_ID_BYTES)()
             rc = L.mcr_comm_unique_id(uid, COMM_ID_BYTES)
             if rc != _ffi.MCR_OK:
                 raise _ffi.McrError(rc, (L.mcr_last_error(None) or b"").decode())
-            tmp = path.with_name(path.name + f".{os.getpid()}.tmp")
-            tmp.write_bytes(bytes(uid))
-            os.replace(tmp, path)                       # atomic: a reader sees all 128 bytes or no file
-        else:
-            t0 = time.monotonic()
-            while True:
-                try:
-                    raw = path.read_bytes()
-                except FileNotFoundError:
-                    raw = b""
-                if len(raw) == COMM_ID_BYTES:
-                    break
-                if time.monotonic() - t0 > timeout:
-                    raise TimeoutError(f"rank {self.rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s")
-                time.sleep(0.01)
-            C.memmove(uid, raw, COMM_ID_BYTES)
+            return bytes(uid)
+
+        raw = exchange_unique_id(self.rank, self.world, make_id, timeout=timeout)
+        uid = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(raw)
         h = C.c_void_p()
-        try:
-            ctx._check(L.mcr_comm_init(ctx.handle, uid, self.world, self.rank, C.byref(h)))   # collective
-        finally:
-            if self.rank == 0:          # init returned on rank 0 => every rank has joined, i.e. has read the file
-                try:
-                    path.unlink()
-                except FileNotFoundError:
-                    pass
+        ctx._check(L.mcr_comm_init(ctx.handle, uid, self.world, self.rank, C.byref(h)))   # collective
         self.handle = h
 
     def all_gather(self, arr: np.ndarray) -> np.ndarray:

@@ -27,7 +27,7 @@ def _free_port() -> int:
 
 @pytest.mark.parametrize("workload", ["c1", "corpus", "c1split"])
 def test_bench_one_rank_over_rccl(workload):
-    env = dict(os.environ, MCR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MCR_BENCH_FORCE_DIST="1")     # (HSA_ENABLE_IPC_MODE_LEGACY=0 is set by _ffi.load_library itself)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "20",
            "--warmup", "2", "--windows", "2", "--no-cpu-baseline", "--no-moments", "--no-probe", "--workload", workload]

@@ -209,11 +209,25 @@ def test_param_block_and_id_file(monkeypatch, tmp_path):
         shard.param_block(4, 2, 2)
     monkeypatch.setenv("MCR_COMM_DIR", str(tmp_path))
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", "29511")
-    monkeypatch.setenv("MCR_COMM_KEY", "k1")
+    for k in ("MCR_COMM_KEY", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"):
+        monkeypatch.delenv(k, raising=False)
     a = shard._id_file(2)
     monkeypatch.setenv("MASTER_PORT", "29512")
     b = shard._id_file(2)
     assert a.parent == tmp_path and a != b and "29511" in a.name and a != shard._id_file(4)
+    assert str(os.getppid()) in a.name                       # no run id: the launcher's pid tells launches apart
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")        # torchrun's default run id is no better than none at all
+    assert shard._id_file(2) == b
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-17")      # a real run id replaces the pid
+    c = shard._id_file(2)
+    assert "job-17" in c.name and str(os.getppid()) not in c.name.replace("29512", "")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert shard._id_file(2) != c
+    monkeypatch.setenv("MCR_COMM_KEY", "my/key:1")           # an explicit key is the whole key
+    d = shard._id_file(2)
+    monkeypatch.setenv("MASTER_PORT", "29513")
+    assert shard._id_file(2) == d and d.name == "mcr_rccl_id_my-key-1"
+    assert shard.comm_key(2)[1] == ["MCR_COMM_KEY=my/key:1"]
 
 
 def test_sorting_network_is_a_sorting_network(tmp_path):
