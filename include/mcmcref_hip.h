@@ -107,6 +107,13 @@ const char* mcr_last_error(const mcr_ctx* ctx); /* ctx may be NULL: last mcr_ini
  * Default: MCR_WORKSPACE_MB env or 8192 MiB. */
 int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes);
 
+/* How many autocorrelation lags this context has re-derived the reference's way so far: the tier-3 scan of the ESS
+ * lags (chains undecided at lag 256) takes no `rho < 0` decision (src/mcmc_ref/diagnostics.py:171-177) on an FFT /
+ * tree-sum value within MCR_RHO_BAND (default 1e-10) of zero; such a lag is recomputed with _autocorr's own left-to-right
+ * sums (diagnostics.py:180-193) first.  A diagnostic: tests use it to show that the guard ran.  Waits for the calls
+ * in flight. */
+int mcr_rho_guard_count(mcr_ctx* ctx, int64_t* rederived);
+
 /* ---- device memory plumbing (for device-resident benchmarking and pipelines) --------- */
 int mcr_dev_alloc(mcr_ctx* ctx, size_t bytes, void** dptr);
 int mcr_dev_free(mcr_ctx* ctx, void* dptr);

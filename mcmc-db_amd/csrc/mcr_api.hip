@@ -117,6 +117,8 @@ struct mcr_ctx {
     bool fft_on = true;      // MCR_FFT=0: long chains take the direct tier-3 rounds only (A/B measurements, parity tests)
     bool f32_records = true; // MCR_F32_RECORDS=0: f32 tensors take the f64 kernels (widened by the tile sort) instead of mcr_sort32.hpp
     int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
+    double rho_band = kRhoBand;   // MCR_RHO_BAND: half-width of the guard band of the tier-3 scan (0 = decide on the raw values)
+    unsigned* guard_count = nullptr;   // device counter: band lags re-derived the reference's way (mcr_rho_guard_count)
     bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
     std::vector<GraphEntry> graphs;
 };
@@ -382,7 +384,7 @@ struct PipeIn {
     double* chstate;     // [pc][2][C][kChState]
     double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products of tier 2 (lags 64..255)
     double* acov;        // [pc][2][n] deviation products of tier 3 (lags >= 256), listed pairs only
-    unsigned* long_count; // [1] number of pairs in the tier-3 list of this call
+    unsigned* long_count; // [2] number of pairs in the tier-3 list of this call; workgroups of k_diag_combine2 that have finished
     unsigned* long_list;  // [2 pc]
     FftPlan fft;          // FFT tier for long chains (mcr_fft.hpp): buffers shared by the chunks of a call
     double2 *fft_A = nullptr, *fft_B = nullptr; double* fft_S = nullptr;
@@ -469,7 +471,8 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
                (const double*)a.state, a.acov, slot_from);
         LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
-               (const unsigned*)a.long_list, a.state, (const double*)a.acov, a.d_res, a.pc);
+               (const unsigned*)a.long_list, a.state, a.acov, a.d_res, a.pc, (const double*)a.kA, (const double*)a.kB, a.M,
+               a.d_off, ctx->rho_band, ctx->guard_count);
         L0 = L1;
     }
     return MCR_OK;
@@ -818,7 +821,8 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
         }
         const size_t slack = 40 * 256 + fp.bytes;
         if (wp.per_param + slack > ctx->ws_limit)
-            return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace; limit is %zu", wp.per_param, ctx->ws_limit);
+            return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace (%zu for the parameter + %zu shared, of which %zu "
+                        "for the FFT tier); limit is %zu", wp.per_param + slack, wp.per_param, slack, fp.bytes, ctx->ws_limit);
         i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
         if (pcmax > P) pcmax = P;
         if (pcmax > kMaxGridY / 2) pcmax = kMaxGridY / 2;   // k_acov_seg uses grid.z = 2 * pc
@@ -856,7 +860,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.more = cv.take<unsigned>((size_t)pc * 2);
                     a.state = cv.take<double>((size_t)pc * 2 * kPairState);
                     a.acov = cv.take<double>((size_t)pc * 2 * (size_t)(N > 0 ? N : 1));
-                    a.long_count = cv.take<unsigned>(1);
+                    a.long_count = cv.take<unsigned>(2);      // list length, finished workgroups of k_diag_combine2
                     a.long_list = cv.take<unsigned>((size_t)pc * 2);
                 }
                 a.nstage = N > 0 ? N : 1;
@@ -1068,6 +1072,13 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
     if (const char* env = getenv("MCR_FFT")) ctx->fft_on = atoi(env) != 0;
+    if (const char* env = getenv("MCR_RHO_BAND")) { const double v = atof(env); if (v >= 0.0 && v < 1.0) ctx->rho_band = v; }
+    if (hipMalloc((void**)&ctx->guard_count, sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(ctx->guard_count, 0, sizeof(unsigned), ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        mcr_free(ctx);
+        return fail(nullptr, MCR_ENOMEM, "device %d: cannot allocate the guard counter", device);
+    }
     if (const char* env = getenv("MCR_SORT_CFG")) {
         const int v = atoi(env);
         if (v >= 0 && v % 10 <= 1 && v / 10 <= 2) ctx->sort_cfg = v;
@@ -1096,6 +1107,7 @@ void mcr_free(mcr_ctx* ctx)
     for (void* w : ctx->lane_ws) if (w) hipFree(w);
     for (const mcr_ctx::ZTab& z : ctx->ztabs) hipFree(z.tab);
     for (const mcr_ctx::Twiddle& t : ctx->twiddles) hipFree(t.tab);
+    if (ctx->guard_count) hipFree(ctx->guard_count);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->pq_stage) hipFree(ctx->pq_stage);
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
@@ -1104,6 +1116,17 @@ void mcr_free(mcr_ctx* ctx)
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
+}
+
+int mcr_rho_guard_count(mcr_ctx* ctx, int64_t* rederived)
+{
+    if (!ctx || !rederived) return fail(ctx, MCR_EINVAL, "NULL argument");
+    hipSetDevice(ctx->device);
+    sync_all(ctx);
+    unsigned v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->guard_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *rederived = (int64_t)v;
+    return MCR_OK;
 }
 
 int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes)
@@ -1320,7 +1343,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.more = cv.take<unsigned>(2);
         a.state = cv.take<double>(2 * kPairState);
         a.acov = cv.take<double>((size_t)2 * (size_t)(n > 0 ? n : 1));
-        a.long_count = cv.take<unsigned>(1);
+        a.long_count = cv.take<unsigned>(2);      // list length, finished workgroups of k_diag_combine2
         a.long_list = cv.take<unsigned>(2);
     }
     a.nstage = nstage;

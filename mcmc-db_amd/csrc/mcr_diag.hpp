@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-    if (pk == 0 && threadIdx.x == 0) *long_count = 0u;     // k_diag_combine2 (a later launch on this stream) appends to the list
+    if (pk == 0 && threadIdx.x == 0) { long_count[0] = 0u; long_count[1] = 0u; }   // list length, finished workgroups of k_diag_combine2 (a later launch on this stream)
 
     double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
     for (int c = w; c < C; c += W) {
@@ -433,29 +433,29 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
 
 // Tier 2 for flagged pairs: lags kLag1..kLag2-1 from the second k_acov_seg pass.  A pair that is still undecided
 // (very sticky chains) gets its deviations z - mean materialised once ([M] doubles per pair: the sort's key
-// buffers, free by now) and a slot in the tier-3 list.  grid (P, 2), block 1024.
-__global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
-                                                       const double* __restrict__ ztab, i64 M,
-                                                       const i64* __restrict__ off, int C, i64 n, int nseg,
-                                                       const double* __restrict__ rec2,
-                                                       const unsigned* __restrict__ more,
-                                                       double* __restrict__ state,
-                                                       const double* __restrict__ chstate,
-                                                       double* __restrict__ res, i64 P,
-                                                       double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                                       unsigned* __restrict__ long_count, unsigned* __restrict__ long_list,
-                                                       const double* __restrict__ part, int ntiles)
+// buffers, free by now) and is marked for tier 3 (state[pk][3] = 0).  grid (P, 2), block 1024.
+//
+// The tier-3 LIST is built in ascending pair order by the workgroup that finishes last (every workgroup counts itself
+// off in long_count[1] behind an agent-scope release; the last one acquires and compacts the marks of all 2 P pairs):
+// which pairs the FFT slots serve (the first fft.slots list entries, mcr_fft.hpp) is then a function of the data alone,
+// not of the order in which workgroups happened to run -- FFT and direct products agree to ~1e-14, not bit for bit, so
+// with an order-dependent list the same call could return different ESS bits from run to run.
+__device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                              const double* __restrict__ ztab, i64 M,
+                                              const i64* __restrict__ off, int C, i64 n, int nseg,
+                                              const double* __restrict__ rec2,
+                                              const unsigned* __restrict__ more,
+                                              double* __restrict__ state,
+                                              const double* __restrict__ chstate,
+                                              double* __restrict__ res, i64 P,
+                                              double* __restrict__ dev_b, double* __restrict__ dev_t,
+                                              double* hb, double (*wcov)[64], double* ctl)
 {
+    constexpr int NW2 = 16;
     const i64 p = blockIdx.x;
     const int kind = blockIdx.y;
     const i64 pk = p * 2 + kind;
-    // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
-    // k_finalize, done here by the first thread of the parameter's first workgroup
-    if (kind == 0 && threadIdx.x == 0) finalize_param(part, ntiles, M, P, C, res, p);
     if (more[pk] == 0u) return;
-    __shared__ double ctl[3];
-    constexpr int NW2 = 16;
-    __shared__ double wcov[NW2][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u32* z = (kind ? zt : zb) + p * M;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
@@ -467,8 +467,6 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
 
     // ---- lags kLag1..kLag2-1, block by block ----
     // hb[c] / tb[c]: running sums of the first / last `lb` draws of chain c (head / tail bases)
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    double* hb = reinterpret_cast<double*>(smem2);
     double* tb = hb + C;
     for (int c = tid; c < C; c += (int)blockDim.x) { hb[c] = chstate[(pk * C + c) * kChState + 3]; tb[c] = chstate[(pk * C + c) * kChState + 4]; }
     __syncthreads();
@@ -535,9 +533,60 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     }
     if (tid == 0) {
         double* stp = state + pk * kPairState;
-        stp[0] = rho_sum; stp[1] = (double)terms; stp[3] = 0.0;
-        long_list[atomicAdd(long_count, 1u)] = (unsigned)pk;     // order of the list is irrelevant: pairs are independent
+        stp[0] = rho_sum; stp[1] = (double)terms; stp[3] = 0.0;     // [3] == 0: on the tier-3 list (built below)
     }
+}
+
+__global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                       const double* __restrict__ ztab, i64 M,
+                                                       const i64* __restrict__ off, int C, i64 n, int nseg,
+                                                       const double* __restrict__ rec2,
+                                                       const unsigned* __restrict__ more,
+                                                       double* __restrict__ state,
+                                                       const double* __restrict__ chstate,
+                                                       double* __restrict__ res, i64 P,
+                                                       double* __restrict__ dev_b, double* __restrict__ dev_t,
+                                                       unsigned* __restrict__ long_count, unsigned* __restrict__ long_list,
+                                                       const double* __restrict__ part, int ntiles)
+{
+    __shared__ double ctl[3];
+    __shared__ double wcov[16][64];
+    __shared__ unsigned s_last, s_wtot[16];
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x;
+    // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
+    // k_finalize, done here by the first thread of the parameter's first workgroup
+    if (blockIdx.y == 0 && tid == 0) finalize_param(part, ntiles, M, P, C, res, blockIdx.x);
+    combine2_pair(zb, zt, ztab, M, off, C, n, nseg, rec2, more, state, chstate, res, P, dev_b, dev_t,
+                  reinterpret_cast<double*>(smem2), wcov, ctl);
+    // ---- count this workgroup off; the last one builds the list in ascending pair order ----
+    __syncthreads();                                       // every store of this workgroup (its mark, its deviations) is issued
+    if (tid == 0) {
+        __threadfence();                                   // agent-scope release of them
+        const unsigned done = atomicAdd(&long_count[1], 1u);
+        s_last = (done + 1u == gridDim.x * gridDim.y) ? 1u : 0u;
+        if (s_last) __threadfence();                       // acquire: the other workgroups' marks
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = tid & 63, w = tid >> 6;
+    const i64 npk = 2 * P;
+    unsigned base = 0;
+    for (i64 k0 = 0; k0 < npk; k0 += 1024) {
+        const i64 pk = k0 + tid;
+        const bool listed = pk < npk && more[pk] != 0u &&
+                            __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&state[pk * kPairState + 3]), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT) == 0ull;      // the bits of +0.0
+        const unsigned long long bal = __ballot(listed);
+        if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = base, total = 0;
+        for (int ww = 0; ww < 16; ++ww) { const unsigned t = s_wtot[ww]; if (ww < w) before += t; total += t; }
+        if (listed) long_list[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)pk;
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) long_count[0] = base;
 }
 
 // Tier 3 products.  grid (lag groups of the round, kLongSlots), block NT.  Workgroup (g, s) takes the listed pairs
@@ -597,14 +646,37 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
 
 // Tier 3 scan of one round's lags [L0, min(L1, n)) for the listed pairs: first negative rho, ordered prefix sum.
 // grid (kLongSlots), block 256.
+//
+// GUARD BAND.  The reference stops at the first `rho < 0` (diagnostics.py:171-177).  The tier-3
+// autocovariances carry round-off -- ~1e-14 rho_0 from the FFTs of mcr_fft.hpp, ~1e-16 rho_0 from the tree sums of
+// k_acov_long -- so a rho that close to zero could take the other sign here than in the reference's own sum, and move the
+// integer truncation lag.  No decision is therefore taken on such a value: the scan looks for the first lag whose rho is
+// below +kRhoBand; if that rho is above -kRhoBand it is RE-DERIVED THE REFERENCE'S WAY before it is compared with zero --
+// per chain one thread adds the rounded products (z_i - m)(z_{i+lag} - m) left to right, no FMA, divides by (n - lag),
+// the chains are added in order (diagnostics.py:185-192) -- and the scan resumes behind it when it is not negative.  With
+// deviations that equal the reference's (they do whenever z does, i.e. outside the 1-2 ulp of the device log in the far
+// tails) this is the reference's own rho bit for bit, whichever engine produced the lag's first estimate; every lag
+// outside the band keeps its FFT / tree value.  A band lag costs one sequential pass over the chain (~0.15 ms for 32 768
+// draws); at most kGuardMax of them are re-derived per pair and round, further ones are decided on the value they have.
+constexpr double kRhoBand = 1e-10;
+constexpr int kGuardMax = 64;
+constexpr int kGuardChunk = 256, kGuardChains = 8;
+
 __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i64 L1,
                                                         const unsigned* __restrict__ long_count,
                                                         const unsigned* __restrict__ long_list,
-                                                        double* __restrict__ state, const double* __restrict__ acov,
-                                                        double* __restrict__ res, i64 P)
+                                                        double* __restrict__ state, double* __restrict__ acov,
+                                                        double* __restrict__ res, i64 P,
+                                                        const double* __restrict__ dev_b, const double* __restrict__ dev_t,
+                                                        i64 M, const i64* __restrict__ off, double band,
+                                                        unsigned* __restrict__ guard_count)
 {
+#pragma clang fp contract(off)      // the re-derived products and sums round like CPython's
     __shared__ double red[4];
     __shared__ long long sfirst;
+    __shared__ double gA[kGuardChains][kGuardChunk], gB[kGuardChains][kGuardChunk];
+    __shared__ double gcov[kGuardChains];
+    __shared__ double gsum;
     const int tid = threadIdx.x;
     const unsigned count = *long_count;
     const i64 lend = (L1 < n) ? L1 : n;
@@ -613,18 +685,66 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
         double* stp = state + pk * kPairState;
         if (stp[3] != 0.0) continue;
         const double vhat = stp[2];
-        const double* a = acov + pk * n;
+        double* a = acov + pk * n;
         const double den = (double)C * vhat;
-        if (tid == 0) sfirst = (long long)lend;
-        __syncthreads();
-        long long mine = (long long)lend;
-        for (i64 l = L0 + tid; l < lend; l += 256) {
-            const double rho = (a[l] / (double)(n - l)) / den;
-            if (rho < 0.0) { mine = l; break; }                    // the thread's lags ascend: its first negative
+        const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
+        i64 from = L0, first = lend;
+        int budget = kGuardMax;
+        for (;;) {
+            if (tid == 0) sfirst = (long long)lend;
+            __syncthreads();
+            long long mine = (long long)lend;
+            for (i64 l = from + tid; l < lend; l += 256) {
+                const double rho = (a[l] / (double)(n - l)) / den;
+                if (rho < band) { mine = l; break; }                   // the thread's lags ascend: its first one below the band's top
+            }
+            if (mine < (long long)lend) atomicMin(&sfirst, mine);
+            __syncthreads();
+            first = (i64)sfirst;
+            if (first >= lend) break;                                  // every remaining lag of the round is clearly positive
+            const double rho_f = (a[first] / (double)(n - first)) / den;
+            if (rho_f < -band || budget == 0) {                        // clearly negative (or out of budget: decided as it stands)
+                if (!(rho_f < 0.0)) { from = first + 1; __syncthreads(); continue; }
+                break;
+            }
+            --budget;
+            // ---- inside the band: the reference's own sum for this lag ----
+            if (tid == 0) gsum = 0.0;
+            for (int c0 = 0; c0 < C; c0 += kGuardChains) {
+                const int nc = (C - c0 < kGuardChains) ? C - c0 : kGuardChains;
+                double cov = 0.0;
+                const i64 len = n - first;
+                for (i64 i0 = 0; i0 < len; i0 += kGuardChunk) {
+                    const int cl = (int)((len - i0 < kGuardChunk) ? len - i0 : kGuardChunk);
+                    __syncthreads();
+                    for (int e = tid; e < nc * kGuardChunk; e += 256) {
+                        const int c = e / kGuardChunk, j = e - c * kGuardChunk;
+                        if (j < cl) {
+                            const double* dc = dev + off[c0 + c];
+                            gA[c][j] = dc[i0 + j]; gB[c][j] = dc[i0 + j + first];
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < nc)
+                        for (int j = 0; j < cl; ++j) cov += gA[tid][j] * gB[tid][j];      // left to right, product rounded first
+                }
+                if (tid < nc) gcov[tid] = cov / (double)len;
+                __syncthreads();
+                if (tid == 0)
+                    for (int c = 0; c < nc; ++c) gsum += gcov[c];                          // chains in order
+                __syncthreads();
+            }
+            const double cov_sum = gsum;
+            const double rho_x = cov_sum / den;
+            if (tid == 0) {
+                a[first] = cov_sum * (double)(n - first);      // what the prefix sum below adds for this lag (sign kept)
+                atomicAdd(guard_count, 1u);
+            }
+            __syncthreads();
+            if (rho_x < 0.0) break;                            // the reference's `if rho < 0: break`
+            from = first + 1;                                  // zero or positive: the walk goes on
         }
-        if (mine < (long long)lend) atomicMin(&sfirst, mine);
         __syncthreads();
-        const i64 first = (i64)sfirst;
         double s = 0.0;
         for (i64 l = L0 + tid; l < first; l += 256) s += (a[l] / (double)(n - l)) / den;
         s = block_sum<256>(s, red);

@@ -72,6 +72,7 @@ SYMBOLS = {
     "mcr_free": (None, [C.c_void_p]),
     "mcr_last_error": (C.c_char_p, [C.c_void_p]),
     "mcr_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mcr_rho_guard_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mcr_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mcr_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -472,6 +473,12 @@ class Context:
         return cov[:P, :P] if P else np.empty((0, 0))
 
     # -- measurement -----------------------------------------------------------------------------
+    def rho_guard_count(self) -> int:
+        """Band lags of the tier-3 ESS scan re-derived with the reference's own sums so far (mcr_rho_guard_count)."""
+        v = C.c_int64(0)
+        self._check(self.lib.mcr_rho_guard_count(self.handle, C.byref(v)))
+        return int(v.value)
+
     def profile(self, on: bool):
         self._check(self.lib.mcr_profile_enable(self.handle, 1 if on else 0))
 

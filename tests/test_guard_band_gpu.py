@@ -1,0 +1,101 @@
+"""Guard band of the tier-3 ESS scan + the order of the tier-3 list.
+
+Spec: src/mcmc_ref/diagnostics.py:154-193 -- `_ess` walks the lags and stops at the first `rho < 0`.  For chains of more
+than 16 384 draws the long lags come from FFTs (csrc/mcr_fft.hpp), whose rho carries ~1e-14 of round-off; the scan
+(k_diag_long_scan, csrc/mcr_diag.hpp) therefore decides no lag whose rho lies within 1e-10 of zero on that value: it
+re-derives the lag with _autocorr's own left-to-right sums first.  tests/golden/band_cases.json holds square-wave
+chains whose rho is exactly zero in exact arithmetic at the deciding lag, with what the IMPORTED REFERENCE returned
+(both outcomes occur: its rounding makes that rho +tiny in some cases, -tiny in others)."""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mcmc_ref_hip import _ffi
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def square_wave(n: int, T: int, shift: int) -> np.ndarray:      # as in tests/golden/make_band_fixture.py
+    i = (np.arange(n) + shift) % T
+    return np.where(i < T // 2, 1.0, -1.0)
+
+
+def _cases():
+    return json.loads((GOLD / "band_cases.json").read_text())["cases"]
+
+
+def test_fft_direct_and_reference_agree_where_rho_is_zero(ctx, oracle, monkeypatch):
+    """FFT tier == direct tier == the reference on the integer truncation lag (and ESS to 1e-12) for every case, and the
+    guard did run: each case has at least one lag inside the band."""
+    from mcmc_ref_hip import _ffi
+    monkeypatch.setenv("MCR_FFT", "0")
+    direct = _ffi.Context(0)
+    monkeypatch.delenv("MCR_FFT")
+    try:
+        outcomes = set()
+        for c in _cases():
+            x = np.stack([square_wave(c["n"], c["T"], s) for s in c["shifts"]])[None]      # [1][C][n]
+            assert c["n"] > 16384 and c["zero_lag"] >= 300
+            exp = oracle.summarize(x, "pcn", min_chains=2)
+            assert int(exp["lag_bulk"][0]) == c["ref_terms"] and float(exp["ess_bulk"][0]) == c["ref_ess_bulk"]
+            outcomes.add(c["ref_terms"] - c["zero_lag"])
+            for cx, name in ((ctx, "fft"), (direct, "direct")):
+                before = cx.rho_guard_count()
+                got = cx.summarize(x, "pcn", min_chains=2)
+                assert int(got["lag_bulk"][0]) == c["ref_terms"], (name, c, int(got["lag_bulk"][0]))
+                assert abs(got["ess_bulk"][0] - c["ref_ess_bulk"]) <= 1e-12 * c["ref_ess_bulk"], (name, c)
+                assert got["ess_tail"][0] == c["C"] * c["n"] and int(got["lag_tail"][0]) == 0    # |x - med| is constant
+                assert cx.rho_guard_count() > before, (name, c)
+        assert outcomes == {0, -1}            # the reference's rounding went both ways across the cases
+    finally:
+        direct.close()
+
+
+def test_without_the_band_the_engines_are_on_their_own(ctx, monkeypatch):
+    """MCR_RHO_BAND=0 switches the re-derivation off: the lag is then decided on the FFT's / the tree sums' own value of
+    a rho that is zero up to round-off.  Nothing is asserted about which way each engine falls -- only that the guard is
+    what the agreement above rests on (the counter stays put) and that the lag stays within one of the reference's."""
+    from mcmc_ref_hip import _ffi
+    monkeypatch.setenv("MCR_RHO_BAND", "0")
+    raw = _ffi.Context(0)
+    monkeypatch.delenv("MCR_RHO_BAND")
+    try:
+        off = 0
+        for c in _cases():
+            x = np.stack([square_wave(c["n"], c["T"], s) for s in c["shifts"]])[None]
+            got = raw.summarize(x, "pcn", min_chains=2)
+            assert abs(int(got["lag_bulk"][0]) - c["ref_terms"]) <= 1
+            off += int(got["lag_bulk"][0]) != c["ref_terms"]
+        assert raw.rho_guard_count() == 0
+        print(f"\nwithout the guard band {off} of {len(_cases())} truncation lags differ from the reference's")
+    finally:
+        raw.close()
+
+
+def test_tier3_list_order_is_a_function_of_the_data(ctx):
+    """36 listed pairs against 32 FFT slots (4 x 17 001 random walks): which pairs the FFT serves must not depend on
+    the order in which workgroups finished -- the list is built in ascending pair order -- so repeated calls return
+    the same bits, and so does a context that works through the parameters in two chunks."""
+    rng = np.random.default_rng(8)
+    x = np.cumsum(rng.normal(size=(18, 4, 17001)), axis=2) * 0.01
+    t = ctx.upload(x, "pcn")
+    try:
+        first = ctx.summarize(t)
+        assert int(first["lag_bulk"].min()) > 256
+        for _ in range(5):
+            again = ctx.summarize(t)
+            for k in ("ess_bulk", "ess_tail", "rhat", "lag_bulk", "lag_tail"):
+                assert np.array_equal(first[k], again[k]), k
+    finally:
+        t.free()
