@@ -53,6 +53,21 @@ ALG_BYTES_PER_PD = {
 }
 
 
+# profile_get() name -> name in profiles/pmc_traffic.json where they differ
+TRAFFIC_NAMES: dict[str, str] = {}
+
+
+def cpu_model() -> str:
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def alg_bytes(name: str, es: int) -> float:
     """Algorithmic bytes per param-draw of one launch of kernel `name` for element size `es`."""
     if name in ("k_tile_sort", "k_moments"):
@@ -423,33 +438,48 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
             # (ctypes releases the GIL; parameters are independent, so this is how a CPU deployment of the
             # restatement would run).  The single-thread rate of the validation pass is reported beside it.
             from concurrent.futures import ThreadPoolExecutor
-            T = max(1, min(16, os.cpu_count() or 1, P))       # 16 = the CPU share of a one-GPU box
-            cuts = [P * i // T for i in range(T + 1)]
-            sl = [(slice(cuts[i], cuts[i + 1]),) if a.layout == "pcn" else (Ellipsis, slice(cuts[i], cuts[i + 1]))
-                  for i in range(T)]
-            parts = [np.ascontiguousarray(host[ix]) for ix in sl]
-            passes, total_s = 0, 0.0
-            with ThreadPoolExecutor(T) as pool:
-                while total_s < 12.0 and passes < 64:
-                    t1 = time.perf_counter()
-                    list(pool.map(lambda x: orc.summarize(x, a.layout), parts))
-                    total_s += time.perf_counter() - t1
-                    passes += 1
-            cpu = {"value": passes * C * N * P / total_s, "unit": "param-draws/s", "cores": T, "kind": "port",
-                   "sample": f"the same {C}x{N}x{P} {a.dtype} model, {passes} passes of oracle/mcr_oracle.c with its "
-                             f"parameters split over {T} threads ({total_s:.1f} s; {os.cpu_count()} cores visible)",
-                   "value_1core": C * N * P / cpu_s}
+
+            def split(T):
+                cuts = [P * i // T for i in range(T + 1)]
+                sl = [(slice(cuts[i], cuts[i + 1]),) if a.layout == "pcn" else (Ellipsis, slice(cuts[i], cuts[i + 1]))
+                      for i in range(T)]
+                return [np.ascontiguousarray(host[ix]) for ix in sl]
+
+            def timed_passes(T, parts, budget_s, fn):
+                passes, total_s = 0, 0.0
+                with ThreadPoolExecutor(T) as pool:
+                    while total_s < budget_s and passes < 64:
+                        t1 = time.perf_counter()
+                        list(pool.map(fn, parts))
+                        total_s += time.perf_counter() - t1
+                        passes += 1
+                return passes, total_s
+
+            ncpu = os.cpu_count() or 1
+            # the restatement on 1 core and on all cores.  `value` = every visible core (one thread per
+            # parameter at most: the parameters are the unit of work), `value_16` = 16 threads, the CPU share of a
+            # one-GPU box on this pool, `value_1core` = the single-threaded validation pass above.
+            T_all = max(1, min(ncpu, P))
+            T = max(1, min(16, ncpu, P))
+            parts = split(T)
+            passes, total_s = timed_passes(T, parts, 8.0, lambda x: orc.summarize(x, a.layout))
+            v16 = passes * C * N * P / total_s
+            if T_all > T:
+                pa, sa = timed_passes(T_all, split(T_all), 8.0, lambda x: orc.summarize(x, a.layout))
+                v_all = pa * C * N * P / sa
+            else:
+                pa, sa, v_all = passes, total_s, v16
+            cpu = {"value": v_all, "unit": "param-draws/s", "cores": T_all, "kind": "port",
+                   "cpu_model": cpu_model(), "cores_visible": ncpu,
+                   "sample": f"the same {C}x{N}x{P} {a.dtype} model through oracle/mcr_oracle.c, its parameters split over "
+                             f"{T_all} threads ({pa} passes, {sa:.1f} s); value_16: over {T} threads ({passes} passes, "
+                             f"{total_s:.1f} s); value_1core: one pass on one thread ({cpu_s:.1f} s)",
+                   "value_16": v16, "cores_16": T, "value_1core": C * N * P / cpu_s}
             if a.layout == "pcn" and a.dtype == "f64" and C >= 2:
                 # the "NumPy CPU path" of SURVEY 8(d): the same statistics vectorised with numpy / scipy
                 # (argsort ranks, ndtri, FFT autocovariances), same thread split, ~6 s sample
                 from oracle import numpy_path
-                npass, nsec = 0, 0.0
-                with ThreadPoolExecutor(T) as pool:
-                    while nsec < 6.0 and npass < 32:
-                        t1 = time.perf_counter()
-                        list(pool.map(numpy_path.summarize, parts))
-                        nsec += time.perf_counter() - t1
-                        npass += 1
+                npass, nsec = timed_passes(T, parts, 6.0, numpy_path.summarize)
                 cpu["numpy_path"] = {"value": npass * C * N * P / nsec, "unit": "param-draws/s", "cores": T,
                                      "sample": f"{npass} passes of oracle/numpy_path.py over {T} threads ({nsec:.1f} s)"}
     valid = ranks.all_true(valid and gathered_ok)
@@ -494,11 +524,18 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
         es = 8 if a.dtype == "f64" else 4
         kern = {}
         dom, dom_ms = None, -1.0
+        ktraffic = traffic_table().get(f"{C}x{N}x{P}-{a.dtype}-{a.layout}", {})
         for name, r in prof.items():
             avg_ms = r["total_ms"] / max(r["launches"], 1)
             alg = alg_bytes(name, es)
+            tb = ktraffic.get(TRAFFIC_NAMES.get(name, name))
             kern[name] = {"launches_per_step": r["launches"] / a.steps, "avg_us": round(avg_ms * 1e3, 2),
-                          "alg_GBps": round(alg * pd_step / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None}
+                          "alg_GBps": round(alg * pd_step / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                          # FETCH_SIZE + WRITE_SIZE of the kernel / its time.  The bytes are per launch from the
+                          # committed rocprofv3 --pmc passes of this configuration (traffic_source below), the time is this
+                          # run's HIP-event average.
+                          "traffic_bytes": tb,
+                          "traffic_GBps": round(tb / (avg_ms * 1e-3) / 1e9, 1) if tb is not None and avg_ms > 0 else None}
             if r["total_ms"] > dom_ms and name in ALG_BYTES_PER_PD:
                 dom, dom_ms = name, r["total_ms"]
         dom_avg_s = prof[dom]["total_ms"] / prof[dom]["launches"] * 1e-3
@@ -530,6 +567,9 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
                          "avg_launch_us": dom_avg_s * 1e6, "alg_bytes_per_launch": dom_alg},
             "hbm_probe": probe,
             "kernels": kern,
+            "kernels_traffic_source": (str(TRAFFIC_FILE.relative_to(ROOT)) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "an earlier run of this configuration, MCR_LANES=1; not counters of this run)") if ktraffic else None,
+            "traffic_bytes_per_step": int(sum(v for k, v in ktraffic.items() if isinstance(v, (int, float)))) if ktraffic else None,
             "moments_roofline": moments,
             "cpu_baseline": cpu,
         }

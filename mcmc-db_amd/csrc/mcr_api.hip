@@ -117,6 +117,7 @@ struct mcr_ctx {
     bool fft_on = true;      // MCR_FFT=0: long chains take the direct tier-3 rounds only (A/B measurements, parity tests)
     bool f32_records = true; // MCR_F32_RECORDS=0: f32 tensors take the f64 kernels (widened by the tile sort) instead of mcr_sort32.hpp
     int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
+    size_t dbg_lds_pad[3] = {0, 0, 0};   // MCR_DBG_LDS_PAD="t,b,f": extra dynamic LDS bytes for tile sort / bucket merge / fold (occupancy experiments)
     double rho_band = kRhoBand;   // MCR_RHO_BAND: half-width of the guard band of the tier-3 scan (0 = decide on the raw values)
     unsigned* guard_count = nullptr;   // device counter: band lags re-derived the reference's way (mcr_rho_guard_count)
     bool graph_on = false;   // MCR_GRAPH=1: capture / replay (measured: no throughput gain, +0.17 ms per synchronous call)
@@ -384,7 +385,7 @@ struct PipeIn {
     double* chstate;     // [pc][2][C][kChState]
     double* rec2;        // [pc][2][C][nseg][64*kMoreBlocks] lag products of tier 2 (lags 64..255)
     double* acov;        // [pc][2][n] deviation products of tier 3 (lags >= 256), listed pairs only
-    unsigned* long_count; // [2] number of pairs in the tier-3 list of this call; workgroups of k_diag_combine2 that have finished
+    unsigned* long_count; // [1] number of pairs in the tier-3 list of this call
     unsigned* long_list;  // [2 pc]
     FftPlan fft;          // FFT tier for long chains (mcr_fft.hpp): buffers shared by the chunks of a call
     double2 *fft_A = nullptr, *fft_B = nullptr; double* fft_S = nullptr;
@@ -434,8 +435,11 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
-           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB, a.long_count, a.long_list,   // kA / kB: the sort's key buffers, free by now
+           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB,   // kA / kB: the sort's key buffers, free by now
            (const double*)a.part, (int)a.ntiles);
+    if (a.n > kLag2)        // chains short enough to be decided by lag 255 never reach tier 3: no list, no tier-3 launches
+        LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
+               a.long_count, a.long_list);
     // tier 3 for the pairs still undecided at lag 256.
     //  * chains of more than 16 384 draws: ALL lags of the first fft.slots listed pairs by FFT (mcr_fft.hpp);
     //  * everything else (and list entries beyond those slots): direct products over the whole chip, in rounds
@@ -497,7 +501,7 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
                lds_tile, (const float*)a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles, samp1);
     } else {
         LAUNCH(ctx, K_TILE_SORT, (k_tile_sort<TNT, TVT, IdxT, double>), dim3((unsigned)a.ntiles, py), dim3(TNT),
-               lds_tile, (const double*)a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles, samp1);
+               lds_tile + ctx->dbg_lds_pad[0], (const double*)a.X, M, a.kA, (IdxT*)a.iA, a.part, (int)a.ntiles, samp1);
     }
     double *kin = a.kA, *kout = a.kB;
     IdxT *iin = (IdxT*)a.iA, *iout = (IdxT*)a.iB;
@@ -525,7 +529,7 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
         LAUNCH(ctx, K_SPLITTERS, k_splitters<double>, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
                M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
-        LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile,
+        LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile + ctx->dbg_lds_pad[1],
                (const double*)kin, (const IdxT*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
                (const u32*)a.boff, a.do_diag ? a.zb : (u32*)nullptr, pc, a.bk_R);
         std::swap(kin, kout);
@@ -548,7 +552,7 @@ int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
 template <typename IdxT, int NT, int VT>
 int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
 {
-    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile),
+    LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + ctx->dbg_lds_pad[2],
            (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, (const double*)a.d_res, a.pc,
            (const i64*)a.split, a.zt);
     return MCR_OK;
@@ -860,7 +864,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.more = cv.take<unsigned>((size_t)pc * 2);
                     a.state = cv.take<double>((size_t)pc * 2 * kPairState);
                     a.acov = cv.take<double>((size_t)pc * 2 * (size_t)(N > 0 ? N : 1));
-                    a.long_count = cv.take<unsigned>(2);      // list length, finished workgroups of k_diag_combine2
+                    a.long_count = cv.take<unsigned>(1);
                     a.long_list = cv.take<unsigned>((size_t)pc * 2);
                 }
                 a.nstage = N > 0 ? N : 1;
@@ -1072,6 +1076,10 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
     if (const char* env = getenv("MCR_FFT")) ctx->fft_on = atoi(env) != 0;
+    if (const char* env = getenv("MCR_DBG_LDS_PAD")) {
+        unsigned long t = 0, b = 0, f = 0;
+        if (sscanf(env, "%lu,%lu,%lu", &t, &b, &f) >= 1) { ctx->dbg_lds_pad[0] = t; ctx->dbg_lds_pad[1] = b; ctx->dbg_lds_pad[2] = f; }
+    }
     if (const char* env = getenv("MCR_RHO_BAND")) { const double v = atof(env); if (v >= 0.0 && v < 1.0) ctx->rho_band = v; }
     if (hipMalloc((void**)&ctx->guard_count, sizeof(unsigned)) != hipSuccess ||
         hipMemsetAsync(ctx->guard_count, 0, sizeof(unsigned), ctx->stream) != hipSuccess ||
@@ -1343,7 +1351,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.more = cv.take<unsigned>(2);
         a.state = cv.take<double>(2 * kPairState);
         a.acov = cv.take<double>((size_t)2 * (size_t)(n > 0 ? n : 1));
-        a.long_count = cv.take<unsigned>(2);      // list length, finished workgroups of k_diag_combine2
+        a.long_count = cv.take<unsigned>(1);
         a.long_list = cv.take<unsigned>(2);
     }
     a.nstage = nstage;

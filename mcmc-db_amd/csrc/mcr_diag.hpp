@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
-    if (pk == 0 && threadIdx.x == 0) { long_count[0] = 0u; long_count[1] = 0u; }   // list length, finished workgroups of k_diag_combine2 (a later launch on this stream)
+    if (pk == 0 && threadIdx.x == 0) long_count[0] = 0u;     // k_long_list (a later launch on this stream) sets the real length
 
     double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
     for (int c = w; c < C; c += W) {
@@ -435,11 +435,12 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
 // (very sticky chains) gets its deviations z - mean materialised once ([M] doubles per pair: the sort's key
 // buffers, free by now) and is marked for tier 3 (state[pk][3] = 0).  grid (P, 2), block 1024.
 //
-// The tier-3 LIST is built in ascending pair order by the workgroup that finishes last (every workgroup counts itself
-// off in long_count[1] behind an agent-scope release; the last one acquires and compacts the marks of all 2 P pairs):
-// which pairs the FFT slots serve (the first fft.slots list entries, mcr_fft.hpp) is then a function of the data alone,
-// not of the order in which workgroups happened to run -- FFT and direct products agree to ~1e-14, not bit for bit, so
-// with an order-dependent list the same call could return different ESS bits from run to run.
+// The tier-3 LIST is built from those marks in ascending pair order by k_long_list (next launch): which pairs the FFT
+// slots serve (the first fft.slots list entries, mcr_fft.hpp) is then a function of the data alone, not of the order in
+// which workgroups happened to run -- FFT and direct products agree to ~1e-14, not bit for bit, so with a list appended
+// to by atomics the same call could return different ESS bits from run to run.  (Measured: building the
+// list here, by the workgroup that finishes last behind agent-scope fences, costs 20 ns per workgroup of the grid --
+// 41 us on 1000 parameters; a launch of its own costs 4.)
 __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                               const double* __restrict__ ztab, i64 M,
                                               const i64* __restrict__ off, int C, i64 n, int nseg,
@@ -546,12 +547,10 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
                                                        const double* __restrict__ chstate,
                                                        double* __restrict__ res, i64 P,
                                                        double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                                       unsigned* __restrict__ long_count, unsigned* __restrict__ long_list,
                                                        const double* __restrict__ part, int ntiles)
 {
     __shared__ double ctl[3];
     __shared__ double wcov[16][64];
-    __shared__ unsigned s_last, s_wtot[16];
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x;
     // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
@@ -559,24 +558,19 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     if (blockIdx.y == 0 && tid == 0) finalize_param(part, ntiles, M, P, C, res, blockIdx.x);
     combine2_pair(zb, zt, ztab, M, off, C, n, nseg, rec2, more, state, chstate, res, P, dev_b, dev_t,
                   reinterpret_cast<double*>(smem2), wcov, ctl);
-    // ---- count this workgroup off; the last one builds the list in ascending pair order ----
-    __syncthreads();                                       // every store of this workgroup (its mark, its deviations) is issued
-    if (tid == 0) {
-        __threadfence();                                   // agent-scope release of them
-        const unsigned done = atomicAdd(&long_count[1], 1u);
-        s_last = (done + 1u == gridDim.x * gridDim.y) ? 1u : 0u;
-        if (s_last) __threadfence();                       // acquire: the other workgroups' marks
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int lane = tid & 63, w = tid >> 6;
+}
+
+// The tier-3 list in ascending pair order: one workgroup compacts the marks of all 2 P pairs.  grid 1, block 1024.
+__global__ __launch_bounds__(1024) void k_long_list(const unsigned* __restrict__ more, const double* __restrict__ state, i64 P,
+                                                   unsigned* __restrict__ long_count, unsigned* __restrict__ long_list)
+{
+    __shared__ unsigned s_wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 npk = 2 * P;
     unsigned base = 0;
     for (i64 k0 = 0; k0 < npk; k0 += 1024) {
         const i64 pk = k0 + tid;
-        const bool listed = pk < npk && more[pk] != 0u &&
-                            __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&state[pk * kPairState + 3]), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT) == 0ull;      // the bits of +0.0
+        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0;
         const unsigned long long bal = __ballot(listed);
         if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
         __syncthreads();
