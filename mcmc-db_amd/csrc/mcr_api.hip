@@ -421,7 +421,7 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     }
     LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64u * (unsigned)(a.C < kCombineWaves ? a.C : kCombineWaves)), (size_t)6 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate,
-           a.long_count);
+           a.long_count, a.long_list);      // (long_list doubles as k_tier3's per-pair counters)
     // tier 2 for pairs whose first negative rho lies beyond lag 63 (others exit at once)
     if (small) {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
@@ -437,9 +437,17 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
            (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB,   // kA / kB: the sort's key buffers, free by now
            (const double*)a.part, (int)a.ntiles);
-    if (a.n > kLag2)        // chains short enough to be decided by lag 255 never reach tier 3: no list, no tier-3 launches
-        LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
-               a.long_count, a.long_list);
+    if (a.n <= kLag2) return MCR_OK;       // chains short enough to be decided by lag 255 never reach tier 3
+    if (!a.fft.on && a.n <= 16384 && 2 * a.pc <= kTier3MaxPairs) {
+        // the common case in one launch: list, products of the single round [256, n) and scan (k_tier3)
+        const unsigned groups = (unsigned)((a.n - kLag2 + kLongGroup - 1) / kLongGroup);
+        const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
+        LAUNCH(ctx, K_ACOV_LONG, k_tier3, dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB, a.M, a.d_off,
+               a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, a.long_list);
+        return MCR_OK;
+    }
+    LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
+           a.long_count, a.long_list);
     // tier 3 for the pairs still undecided at lag 256.
     //  * chains of more than 16 384 draws: ALL lags of the first fft.slots listed pairs by FFT (mcr_fft.hpp);
     //  * everything else (and list entries beyond those slots): direct products over the whole chip, in rounds
@@ -511,8 +519,8 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     const i64 Rstop = bucket ? a.bk_R : M;
     for (i64 R = kTile; R < Rstop; R *= 2) {
         LAUNCH(ctx, K_MERGE, (k_merge<MNT, MVT, false, IdxT>), dim3(nblk, py), dim3(MNT), lds_tile + 256,
-               (const double*)kin, (const IdxT*)iin, kout, iout, M, R, (const double*)nullptr, pc,
-               (const i64*)nullptr, (u32*)nullptr);
+               (const double*)kin, (const IdxT*)iin, kout, iout, M, R, (double*)nullptr, pc,
+               QArgs{}, (u32*)nullptr);
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
@@ -544,8 +552,8 @@ template <typename IdxT, int NT, int VT>
 int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
 {
     LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT, u64>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile),
-           (const u64*)kin, (const IdxT*)nullptr, (double*)nullptr, (IdxT*)nullptr, a.M, (i64)0, (const double*)a.d_res, a.pc,
-           (const i64*)a.split, a.zt);
+           (const u64*)kin, (const IdxT*)nullptr, (double*)nullptr, (IdxT*)nullptr, a.M, (i64)0, a.d_res, a.pc,
+           a.q, a.zt);
     return MCR_OK;
 }
 
@@ -553,8 +561,8 @@ template <typename IdxT, int NT, int VT>
 int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, void* iout, unsigned fgrid)
 {
     LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + ctx->dbg_lds_pad[2],
-           (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, (const double*)a.d_res, a.pc,
-           (const i64*)a.split, a.zt);
+           (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, a.d_res, a.pc,
+           a.q, a.zt);
     return MCR_OK;
 }
 
@@ -661,13 +669,15 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         const int rc = sort_stage(ctx, a, &kin, &iin, &kout, &iout, &ranked);
         if (rc) return rc;
     }
-    // 3. order statistics
-    if (use_records(a)) {
-        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
-               (const u64*)kin, M, pc, a.q, a.d_res, a.split);
-    } else {
-        LAUNCH(ctx, K_ORDER_STATS, k_order_stats<double>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
-               (const double*)kin, M, pc, a.q, a.d_res, a.split);
+    // 3. order statistics: with diagnostics, by the fold kernel itself; a launch of their own for Backend.stats calls
+    if (!a.do_diag) {
+        if (use_records(a)) {
+            LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
+                   (const u64*)kin, M, pc, a.q, a.d_res, a.split);
+        } else {
+            LAUNCH(ctx, K_ORDER_STATS, k_order_stats<double>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
+                   (const double*)kin, M, pc, a.q, a.d_res, a.split);
+        }
     }
     if (a.do_diag) {
         // 4. bulk ranks -> z (already done by k_bucket_merge on the bucket path)

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
                                                      int nseg, const double* __restrict__ rec,
                                                      double* __restrict__ res, i64 P, unsigned* __restrict__ more,
                                                      double* __restrict__ state, double* __restrict__ chstate,
-                                                     unsigned* __restrict__ long_count)
+                                                     unsigned* __restrict__ long_count, unsigned* __restrict__ pair_done)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* cm = reinterpret_cast<double*>(smem);   // C   chain means
@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
     if (pk == 0 && threadIdx.x == 0) long_count[0] = 0u;     // k_long_list (a later launch on this stream) sets the real length
+    if (pair_done != nullptr && threadIdx.x == 0) pair_done[pk] = 0u;  // k_tier3: lag groups that have finished this pair
 
     double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
     for (int c = w; c < C; c += W) {
@@ -588,6 +589,49 @@ __global__ __launch_bounds__(1024) void k_long_list(const unsigned* __restrict__
 // [L0 + 256 g, L0 + 256 g + 256) in registers (4 blocks of 64 lags: one staging of the segment serves 256 lags),
 // then writes acov[pair][lag] = sum_c sum_i d_c[i] d_c[i + lag] once.  Deterministic: fixed summation order.
 template <int NT>
+struct LongLds {
+    static constexpr int SEG = kSeg;
+    static constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + kLongGroup + 16) / 8 * 10;
+    double sA[LA];
+    double sB[LB];
+    double tot[64];
+    double wred[NT / kWave * 64];
+};
+
+// One listed pair, one group of 256 lags [lbase, lbase + 256) (clipped to lend).  All NT threads call it.
+template <int NT>
+__device__ __forceinline__ void acov_long_pair(const double* __restrict__ dev, const i64* __restrict__ off, int C, i64 n,
+                                               i64 lbase, i64 lend, double* __restrict__ out, LongLds<NT>& L)
+{
+    constexpr int SEG = kSeg;
+    const int tid = threadIdx.x;
+    double acc[4][8];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[b][i] = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const double* dc = dev + off[c];
+        for (i64 s0 = 0; s0 + lbase < n; s0 += SEG) {           // beyond that every product has a factor past the chain
+            const int seglen = (int)((n - s0 < (i64)SEG) ? n - s0 : (i64)SEG);
+            __syncthreads();
+            for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; L.sA[pos8(j)] = (g < n) ? dc[g] : 0.0; }
+            for (int j = tid; j < SEG + kLongGroup + 16; j += NT) { const i64 g = s0 + lbase + j; L.sB[pos8(j)] = (g < n) ? dc[g] : 0.0; }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) seg_accumulate<NT, 8>(L.sA, L.sB + 80 * b, seglen, acc[b]);     // 64 draws = 80 swizzled slots
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        seg_reduce<NT, 8>(acc[b], L.tot, L.wred);
+        const i64 lag = lbase + 64 * b + tid;
+        if (tid < 64 && lag < lend) out[lag] = L.tot[tid];
+        __syncthreads();
+    }
+}
+
+template <int NT>
 __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev_b, const double* __restrict__ dev_t,
                                                   i64 M, const i64* __restrict__ off, int C, i64 n, i64 L0, i64 L1,
                                                   const unsigned* __restrict__ long_count,
@@ -595,13 +639,7 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
                                                   const double* __restrict__ state, double* __restrict__ acov,
                                                   unsigned slot_from)
 {
-    constexpr int NW = NT / kWave, SEG = kSeg;
-    constexpr int LA = (SEG + 16) / 8 * 10, LB = (SEG + kLongGroup + 16) / 8 * 10;
-    __shared__ __attribute__((aligned(16))) double sA[LA];
-    __shared__ __attribute__((aligned(16))) double sB[LB];
-    __shared__ double tot[64];
-    __shared__ double wred[NW * 64];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) LongLds<NT> L;
     const unsigned count = *long_count;
     const i64 lend = (L1 < n) ? L1 : n;
     const i64 lbase = L0 + (i64)kLongGroup * blockIdx.x;
@@ -609,32 +647,7 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
     for (unsigned slot = slot_from + blockIdx.y; slot < count; slot += gridDim.y) {     // entries below slot_from: served by the FFT tier
         const i64 pk = long_list[slot];
         if (state[pk * kPairState + 3] != 0.0) continue;            // decided in an earlier round
-        const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
-        double acc[4][8];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[b][i] = 0.0;
-        for (int c = 0; c < C; ++c) {
-            const double* dc = dev + off[c];
-            for (i64 s0 = 0; s0 + lbase < n; s0 += SEG) {           // beyond that every product has a factor past the chain
-                const int seglen = (int)((n - s0 < (i64)SEG) ? n - s0 : (i64)SEG);
-                __syncthreads();
-                for (int j = tid; j < SEG + 16; j += NT) { const i64 g = s0 + j; sA[pos8(j)] = (g < n) ? dc[g] : 0.0; }
-                for (int j = tid; j < SEG + kLongGroup + 16; j += NT) { const i64 g = s0 + lbase + j; sB[pos8(j)] = (g < n) ? dc[g] : 0.0; }
-                __syncthreads();
-#pragma unroll
-                for (int b = 0; b < 4; ++b) seg_accumulate<NT, 8>(sA, sB + 80 * b, seglen, acc[b]);     // 64 draws = 80 swizzled slots
-            }
-        }
-        double* out = acov + pk * n;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            seg_reduce<NT, 8>(acc[b], tot, wred);
-            const i64 lag = lbase + 64 * b + tid;
-            if (tid < 64 && lag < lend) out[lag] = tot[tid];
-            __syncthreads();
-        }
+        acov_long_pair<NT>(((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M, off, C, n, lbase, lend, acov + pk * n, L);
     }
 }
 
@@ -656,6 +669,102 @@ constexpr double kRhoBand = 1e-10;
 constexpr int kGuardMax = 64;
 constexpr int kGuardChunk = 256, kGuardChains = 8;
 
+struct ScanLds {
+    double red[4];
+    long long sfirst;
+    double gA[kGuardChains][kGuardChunk], gB[kGuardChains][kGuardChunk];
+    double gcov[kGuardChains];
+    double gsum;
+};
+
+// The scan of one listed pair over the lags [L0, lend).  All 256 threads call it.
+__device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64 lend, double* __restrict__ state,
+                                               double* __restrict__ acov, double* __restrict__ res, i64 P,
+                                               const double* __restrict__ dev, const i64* __restrict__ off, double band,
+                                               unsigned* __restrict__ guard_count, ScanLds& S)
+{
+#pragma clang fp contract(off)      // the re-derived products and sums round like CPython's
+    const int tid = threadIdx.x;
+    double* stp = state + pk * kPairState;
+    const double vhat = stp[2];
+    double* a = acov + pk * n;
+    const double den = (double)C * vhat;
+    i64 from = L0, first = lend;
+    int budget = kGuardMax;
+    for (;;) {
+        if (tid == 0) S.sfirst = (long long)lend;
+        __syncthreads();
+        long long mine = (long long)lend;
+        for (i64 l = from + tid; l < lend; l += 256) {
+            const double rho = (a[l] / (double)(n - l)) / den;
+            if (rho < band) { mine = l; break; }                   // the thread's lags ascend: its first one below the band's top
+        }
+        if (mine < (long long)lend) atomicMin(&S.sfirst, mine);
+        __syncthreads();
+        first = (i64)S.sfirst;
+        if (first >= lend) break;                                  // every remaining lag of the round is clearly positive
+        const double rho_f = (a[first] / (double)(n - first)) / den;
+        if (rho_f < -band || budget == 0) {                        // clearly negative (or out of budget: decided as it stands)
+            if (!(rho_f < 0.0)) { from = first + 1; __syncthreads(); continue; }
+            break;
+        }
+        --budget;
+        // ---- inside the band: the reference's own sum for this lag ----
+        if (tid == 0) S.gsum = 0.0;
+        for (int c0 = 0; c0 < C; c0 += kGuardChains) {
+            const int nc = (C - c0 < kGuardChains) ? C - c0 : kGuardChains;
+            double cov = 0.0;
+            const i64 len = n - first;
+            for (i64 i0 = 0; i0 < len; i0 += kGuardChunk) {
+                const int cl = (int)((len - i0 < kGuardChunk) ? len - i0 : kGuardChunk);
+                __syncthreads();
+                for (int e = tid; e < nc * kGuardChunk; e += 256) {
+                    const int c = e / kGuardChunk, j = e - c * kGuardChunk;
+                    if (j < cl) {
+                        const double* dc = dev + off[c0 + c];
+                        S.gA[c][j] = dc[i0 + j]; S.gB[c][j] = dc[i0 + j + first];
+                    }
+                }
+                __syncthreads();
+                if (tid < nc)
+                    for (int j = 0; j < cl; ++j) cov += S.gA[tid][j] * S.gB[tid][j];      // left to right, product rounded first
+            }
+            if (tid < nc) S.gcov[tid] = cov / (double)len;
+            __syncthreads();
+            if (tid == 0)
+                for (int c = 0; c < nc; ++c) S.gsum += S.gcov[c];                          // chains in order
+            __syncthreads();
+        }
+        const double cov_sum = S.gsum;
+        const double rho_x = cov_sum / den;
+        if (tid == 0) {
+            a[first] = cov_sum * (double)(n - first);      // what the prefix sum below adds for this lag (sign kept)
+            atomicAdd(guard_count, 1u);
+        }
+        __syncthreads();
+        if (rho_x < 0.0) break;                            // the reference's `if rho < 0: break`
+        from = first + 1;                                  // zero or positive: the walk goes on
+    }
+    __syncthreads();
+    double s = 0.0;
+    for (i64 l = L0 + tid; l < first; l += 256) s += (a[l] / (double)(n - l)) / den;
+    s = block_sum<256>(s, S.red);
+    if (tid == 0) {
+        const double rho_sum = stp[0] + s;
+        const double terms = stp[1] + (double)(first - L0);
+        if (first < lend || lend >= n) {
+            const i64 p = pk >> 1;
+            const int kind = (int)(pk & 1);
+            res[(kind ? R_ESS_TAIL : R_ESS_BULK) * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
+            res[(kind ? R_LAG_TAIL : R_LAG_BULK) * P + p] = terms;
+            stp[3] = 1.0;
+        } else {
+            stp[0] = rho_sum; stp[1] = terms;
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i64 L1,
                                                         const unsigned* __restrict__ long_count,
                                                         const unsigned* __restrict__ long_list,
@@ -665,96 +774,70 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
                                                         i64 M, const i64* __restrict__ off, double band,
                                                         unsigned* __restrict__ guard_count)
 {
-#pragma clang fp contract(off)      // the re-derived products and sums round like CPython's
-    __shared__ double red[4];
-    __shared__ long long sfirst;
-    __shared__ double gA[kGuardChains][kGuardChunk], gB[kGuardChains][kGuardChunk];
-    __shared__ double gcov[kGuardChains];
-    __shared__ double gsum;
-    const int tid = threadIdx.x;
+    __shared__ ScanLds S;
     const unsigned count = *long_count;
     const i64 lend = (L1 < n) ? L1 : n;
     for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
         const i64 pk = long_list[slot];
-        double* stp = state + pk * kPairState;
-        if (stp[3] != 0.0) continue;
-        const double vhat = stp[2];
-        double* a = acov + pk * n;
-        const double den = (double)C * vhat;
+        if (state[pk * kPairState + 3] != 0.0) continue;
+        long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M, off, band,
+                       guard_count, S);
+    }
+}
+
+// Tier 3 in ONE launch for chains of at most 16 384 draws (a single round of lags [256, n), no FFT) and at most
+// kTier3MaxPairs pairs per chunk -- what every call of the C1 shape and of the packaged corpus takes, nearly always with
+// nothing listed.  grid (lag groups, kLongSlots), block 256.  Every workgroup compacts the tier-3 marks of the 2 P
+// pairs into its own LDS in ascending pair order (the list k_long_list would build; with nothing listed it is done
+// after one round of loads), takes the products of its 256 lags for the pairs of its slot, and counts itself off per
+// pair behind an agent-scope release; the workgroup that finishes a pair's last lag group acquires and runs the scan
+// (first negative rho with the guard band, ordered prefix sum).  Three launches of round 2 -- list, products, scan --
+// in one; the fences are paid by workgroups that have a listed pair to work on, nobody else.
+constexpr int kTier3MaxPairs = 2048;
+union Tier3Lds {
+    LongLds<256> L;
+    ScanLds S;
+};
+__global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b, const double* __restrict__ dev_t, i64 M,
+                                               const i64* __restrict__ off, int C, i64 n, const unsigned* __restrict__ more,
+                                               double* __restrict__ state, double* __restrict__ acov, double* __restrict__ res,
+                                               i64 P, double band, unsigned* __restrict__ guard_count,
+                                               unsigned* __restrict__ pair_done)
+{
+    __shared__ __attribute__((aligned(16))) Tier3Lds U;
+    __shared__ unsigned short slist[kTier3MaxPairs];
+    __shared__ unsigned s_wtot[4], s_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 npk = 2 * P;
+    unsigned count = 0;
+    for (i64 k0 = 0; k0 < npk; k0 += 256) {
+        const i64 pk = k0 + tid;
+        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0;
+        const unsigned long long bal = __ballot(listed);
+        if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = count, total = 0;
+        for (int ww = 0; ww < 4; ++ww) { const unsigned t = s_wtot[ww]; if (ww < w) before += t; total += t; }
+        if (listed) slist[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)pk;
+        count += total;
+        __syncthreads();
+    }
+    if (count == 0) return;
+    const i64 lend = n;                                   // n <= 16 384: the round [kLag2, 16 384) covers every lag
+    const i64 lbase = kLag2 + (i64)kLongGroup * blockIdx.x;
+    for (unsigned slot = blockIdx.y; slot < count; slot += gridDim.y) {
+        const i64 pk = slist[slot];
         const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
-        i64 from = L0, first = lend;
-        int budget = kGuardMax;
-        for (;;) {
-            if (tid == 0) sfirst = (long long)lend;
-            __syncthreads();
-            long long mine = (long long)lend;
-            for (i64 l = from + tid; l < lend; l += 256) {
-                const double rho = (a[l] / (double)(n - l)) / den;
-                if (rho < band) { mine = l; break; }                   // the thread's lags ascend: its first one below the band's top
-            }
-            if (mine < (long long)lend) atomicMin(&sfirst, mine);
-            __syncthreads();
-            first = (i64)sfirst;
-            if (first >= lend) break;                                  // every remaining lag of the round is clearly positive
-            const double rho_f = (a[first] / (double)(n - first)) / den;
-            if (rho_f < -band || budget == 0) {                        // clearly negative (or out of budget: decided as it stands)
-                if (!(rho_f < 0.0)) { from = first + 1; __syncthreads(); continue; }
-                break;
-            }
-            --budget;
-            // ---- inside the band: the reference's own sum for this lag ----
-            if (tid == 0) gsum = 0.0;
-            for (int c0 = 0; c0 < C; c0 += kGuardChains) {
-                const int nc = (C - c0 < kGuardChains) ? C - c0 : kGuardChains;
-                double cov = 0.0;
-                const i64 len = n - first;
-                for (i64 i0 = 0; i0 < len; i0 += kGuardChunk) {
-                    const int cl = (int)((len - i0 < kGuardChunk) ? len - i0 : kGuardChunk);
-                    __syncthreads();
-                    for (int e = tid; e < nc * kGuardChunk; e += 256) {
-                        const int c = e / kGuardChunk, j = e - c * kGuardChunk;
-                        if (j < cl) {
-                            const double* dc = dev + off[c0 + c];
-                            gA[c][j] = dc[i0 + j]; gB[c][j] = dc[i0 + j + first];
-                        }
-                    }
-                    __syncthreads();
-                    if (tid < nc)
-                        for (int j = 0; j < cl; ++j) cov += gA[tid][j] * gB[tid][j];      // left to right, product rounded first
-                }
-                if (tid < nc) gcov[tid] = cov / (double)len;
-                __syncthreads();
-                if (tid == 0)
-                    for (int c = 0; c < nc; ++c) gsum += gcov[c];                          // chains in order
-                __syncthreads();
-            }
-            const double cov_sum = gsum;
-            const double rho_x = cov_sum / den;
-            if (tid == 0) {
-                a[first] = cov_sum * (double)(n - first);      // what the prefix sum below adds for this lag (sign kept)
-                atomicAdd(guard_count, 1u);
-            }
-            __syncthreads();
-            if (rho_x < 0.0) break;                            // the reference's `if rho < 0: break`
-            from = first + 1;                                  // zero or positive: the walk goes on
+        if (lbase < lend) acov_long_pair<256>(dev, off, C, n, lbase, lend, acov + pk * n, U.L);
+        __syncthreads();                                  // every store of this workgroup's lags is issued
+        if (tid == 0) {
+            __threadfence();                              // agent-scope release of them
+            const unsigned done = atomicAdd(&pair_done[pk], 1u);
+            s_last = (done + 1u == gridDim.x) ? 1u : 0u;
+            if (s_last) __threadfence();                  // acquire: the other groups' lags
         }
         __syncthreads();
-        double s = 0.0;
-        for (i64 l = L0 + tid; l < first; l += 256) s += (a[l] / (double)(n - l)) / den;
-        s = block_sum<256>(s, red);
-        if (tid == 0) {
-            const double rho_sum = stp[0] + s;
-            const double terms = stp[1] + (double)(first - L0);
-            if (first < lend || lend >= n) {
-                const i64 p = pk >> 1;
-                const int kind = (int)(pk & 1);
-                res[(kind ? R_ESS_TAIL : R_ESS_BULK) * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
-                res[(kind ? R_LAG_TAIL : R_LAG_BULK) * P + p] = terms;
-                stp[3] = 1.0;
-            } else {
-                stp[0] = rho_sum; stp[1] = terms;
-            }
-        }
+        if (s_last) long_scan_pair(pk, C, n, (i64)kLag2, lend, state, acov, res, P, dev, off, band, guard_count, U.S);
         __syncthreads();
     }
 }

@@ -568,6 +568,39 @@ __device__ __forceinline__ void block_tie_runs(KF key_at, int total, int* wsh, i
     __syncthreads();
 }
 
+// Order statistics of one parameter by ONE WAVE from its pooled ascending keys: quantiles (numpy `linear` lerp, which
+// pyarrow's interpolation="linear" agrees with to 1 ulp; src/mcmc_ref/backends_numpy.py:44, backends_arrow.py:40-42),
+// statistics.median (diagnostics.py:97) and the fold split point s = #(x < med), found by a 64-ary search (64 probes and
+// a ballot per round: three dependent loads for 40 000 draws where a bisection needs sixteen).  Returns s in every lane;
+// `write`: also store the quantiles and the median into the result table (one caller per parameter does).
+template <typename KT>
+__device__ __forceinline__ i64 wave_order_stats(const KT* __restrict__ k, i64 M, const QArgs& q, bool write,
+                                                double* __restrict__ res, i64 P, i64 p, double& med_out)
+{
+#pragma clang fp contract(off)  // the lerp must round like numpy's (separate multiply and add)
+    const int lane = threadIdx.x & 63;
+    if (write && lane < q.nq) {
+        const int j = lane;
+        const i64 lo = q.lo[j], hi = (lo + 1 < M) ? lo + 1 : M - 1;
+        const double a = sorted_key(k, lo), b = sorted_key(k, hi), d = b - a, g = q.g[j];
+        res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
+    }
+    const double med = (M & 1) ? sorted_key(k, M / 2) : (sorted_key(k, M / 2 - 1) + sorted_key(k, M / 2)) / 2.0;
+    if (write && lane == 0) res[R_MEDIAN * P + p] = med;
+    i64 lo = 0, hi = M;  // first index with k[i] >= med lies in [lo, hi]
+    while (lo < hi) {
+        const i64 step = (hi - lo + 63) / 64;
+        const i64 pos = lo + step * (lane + 1) - 1;                 // ascending probes, the last one at or beyond hi - 1
+        const bool less = (pos < hi) && (sorted_key(k, pos) < med);
+        const i64 cnt = (i64)__popcll(__ballot(less));              // sorted keys: the first cnt probes are below med
+        const i64 nhi = lo + step * (cnt + 1) - 1;                  // probe cnt (if any) is the first one not below
+        lo += step * cnt;
+        hi = (nhi < hi) ? nhi : hi;
+    }
+    med_out = med;
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Merge pass.  FOLD == false: merges pairs of sorted runs of length R (merge sort pass).
 // FOLD == true : produces the ascending order of |x - med| from the ascending order of x with a
@@ -580,8 +613,8 @@ __device__ __forceinline__ void block_tie_runs(KF key_at, int total, int* wsh, i
 template <int NT, int VT, bool FOLD, typename IdxT, typename KT = double>
 __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const IdxT* __restrict__ iin,
                                               double* __restrict__ kout, IdxT* __restrict__ iout, i64 M,
-                                              i64 R, const double* __restrict__ res, i64 P,
-                                              const i64* __restrict__ split, u32* __restrict__ z)
+                                              i64 R, double* __restrict__ res, i64 P,
+                                              QArgs q, u32* __restrict__ z)
 {
     constexpr int OBS = NT * VT;                            // LDS slots
     // The fold kernel owns 64 outputs fewer than it has slots and keeps its scratch in the 64 key slots that frees:
@@ -617,8 +650,18 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
         nb = (M - bbase < R) ? M - bbase : R;
         d0 = o0 - pb;
     } else {
-        const i64 s = split[p];
-        med = res[R_MEDIAN * P + p];
+        // The order statistics of the parameter, by the first wave of EVERY fold workgroup (a launch of their own in round
+        // 2): the median and the split point are three to five dependent loads, the parameter's first workgroup also
+        // writes the quantiles and the median.
+        if (tid < 64) {
+            double m_;
+            const i64 s_ = wave_order_stats(kp, M, q, blk == 0, res, P, p, m_);
+            if (tid == 0) { sh[0] = s_; reinterpret_cast<double*>(sh)[1] = m_; }
+        }
+        __syncthreads();
+        const i64 s = sh[0];
+        med = reinterpret_cast<double*>(sh)[1];
+        __syncthreads();
         abase = s - 1;  // walked downwards
         na = s;
         bbase = s;
@@ -1043,30 +1086,12 @@ template <typename KT>
 __global__ __launch_bounds__(256) void k_order_stats(const KT* __restrict__ keys, i64 M, i64 P, QArgs q,
                                                      double* __restrict__ res, i64* __restrict__ split)
 {
-#pragma clang fp contract(off)  // the lerp must round like numpy's (separate multiply and add)
     const int lane = threadIdx.x & 63;
     const i64 p = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
-    const KT* k = keys + p * M;
-    if (lane < q.nq) {
-        const int j = lane;
-        const i64 lo = q.lo[j], hi = (lo + 1 < M) ? lo + 1 : M - 1;
-        const double a = sorted_key(k, lo), b = sorted_key(k, hi), d = b - a, g = q.g[j];
-        res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
-    }
-    const double med = (M & 1) ? sorted_key(k, M / 2) : (sorted_key(k, M / 2 - 1) + sorted_key(k, M / 2)) / 2.0;
-    if (lane == 0) res[R_MEDIAN * P + p] = med;
-    i64 lo = 0, hi = M;  // first index with k[i] >= med lies in [lo, hi]
-    while (lo < hi) {
-        const i64 step = (hi - lo + 63) / 64;
-        const i64 pos = lo + step * (lane + 1) - 1;                 // ascending probes, the last one at or beyond hi - 1
-        const bool less = (pos < hi) && (sorted_key(k, pos) < med);
-        const i64 cnt = (i64)__popcll(__ballot(less));              // sorted keys: the first cnt probes are below med
-        const i64 nhi = lo + step * (cnt + 1) - 1;                  // probe cnt (if any) is the first one not below
-        lo += step * cnt;
-        hi = (nhi < hi) ? nhi : hi;
-    }
-    if (lane == 0) split[p] = lo;
+    double med;
+    const i64 s = wave_order_stats(keys + p * M, M, q, true, res, P, p, med);
+    if (lane == 0) split[p] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
