@@ -1590,10 +1590,14 @@ int mcr_covariance_dev(mcr_ctx* ctx, const double* draws_dev, int64_t M, int64_t
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int nb = (int)((P + kCovBM - 1) / kCovBM);
     const i64 P64 = (i64)nb * kCovBM;
-    const i64 tiles = (i64)nb * (nb + 1) / 2;                        // workgroups that do work per draw slice
-    int ksplit = (int)((1024 + tiles - 1) / tiles);                  // >= ~1024 workgroups: 2 per CU, two rounds
-    const i64 maxsplit = (M + 8 * kCovBK - 1) / (8 * kCovBK);        // a slice is at least 8 panels long
+    const i64 tiles = (i64)nb * (nb + 1) / 2;                        // workgroups per draw slice (none below the diagonal)
+    int ksplit = (int)((512 + tiles - 1) / tiles);                   // >= ~512 workgroups: two per CU
+    const i64 maxsplit = (M + 16 * kCovBK - 1) / (16 * kCovBK);      // a slice is at least 16 panels long
     if (ksplit > maxsplit) ksplit = (int)maxsplit;
+    {   // the slices' partial tiles are summed by k_cov_final: at most 128 MB of them
+        const i64 cap = ((i64)128 << 20) / (P64 * P64 * 8);
+        if (ksplit > cap) ksplit = (int)(cap < 1 ? 1 : cap);
+    }
     if (ksplit < 1) ksplit = 1;
     i64 kchunk = (M + ksplit - 1) / ksplit;
     kchunk = (kchunk + kCovBK - 1) / kCovBK * kCovBK;
@@ -1610,10 +1614,10 @@ int mcr_covariance_dev(mcr_ctx* ctx, const double* draws_dev, int64_t M, int64_t
     rc = moments_impl<double>(ctx, draws_dev, 1, M, P, M, 1, M, d_mean, d_std, mpart, (M >= 8 * 2048) ? S : 1, true);
     if (rc) return rc;
     if ((M & 1) == 0 && (reinterpret_cast<uintptr_t>(draws_dev) & 15) == 0) {
-        LAUNCH(ctx, K_COV, (k_cov_mfma<true>), dim3((unsigned)(nb * nb), (unsigned)ksplit), dim3(256), 0, draws_dev,
+        LAUNCH(ctx, K_COV, (k_cov_mfma<true>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, draws_dev,
                (const double*)d_mean, (i64)M, (i64)P, nb, kchunk, partial);
     } else {
-        LAUNCH(ctx, K_COV, (k_cov_mfma<false>), dim3((unsigned)(nb * nb), (unsigned)ksplit), dim3(256), 0, draws_dev,
+        LAUNCH(ctx, K_COV, (k_cov_mfma<false>), dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, draws_dev,
                (const double*)d_mean, (i64)M, (i64)P, nb, kchunk, partial);
     }
     LAUNCH(ctx, K_COV_FINAL, k_cov_final, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, (const double*)partial,

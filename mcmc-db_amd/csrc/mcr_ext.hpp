@@ -110,81 +110,86 @@ __global__ void k_bad_count(const double* __restrict__ part, int ntiles, i64 P, 
 // the one place the matrix cores are used.  G = (X - mu)(X - mu)^T with X [P][M] row-major (mu_p from the streaming
 // moments kernel, so G / M IS the covariance: no correction term), v_mfma_f64_16x16x4f64.
 //
-// A SYRK-shaped tiling for gfx950: a 256-thread workgroup owns a 64 x 64 tile of G (upper triangle only; the finisher
-// mirrors it) and one slice of the draw axis.  Per step of 32 draws the two 64 x 32 operand panels go global -> registers
-// (two 8-byte loads per lane, 256 contiguous bytes per row: coalesced) -> centred -> LDS with a row stride of 34 doubles,
-// which makes the one-double-per-lane operand fetch of the MFMA (lane 16k + i reads row i, draw k) conflict-free
-// (16 rows x 272 bytes hit 16 different 8-byte bank pairs).  Double buffered: the loads of panel s + 1 are in flight while
-// the 32 MFMAs of panel s run.  Each of the 4 waves owns a 32 x 32 quadrant = 2 x 2 MFMA tiles, so every operand
-// register feeds two MFMAs (4 LDS reads per 4 MFMAs per wave and step of 4 draws).
-// grid (nb * nb, ksplit) with nb = ceil(P / 64); workgroups below the diagonal exit at once.  partial[ks][P64][P64].
+// A SYRK-shaped tiling for gfx950: a 256-thread workgroup owns a 128 x 128 tile of G (upper triangle only, the grid
+// holds no workgroup below the diagonal; the finisher mirrors) and one slice of the draw axis.  Per step of 16 draws the
+// two 128 x 16 operand panels go global -> registers (four 16-byte loads per lane and panel, a whole 128-byte line per
+// row) -> centred -> LDS with a row stride of 18 doubles, which makes the one-double-per-lane operand fetch of the MFMA
+// (lane 16 k + i reads row i, draw k) conflict-free.  Double buffered: the loads of panel s + 1 are in flight while the
+// 64 MFMAs of panel s run.  Each of the 4 waves owns a 64 x 64 quadrant = 4 x 4 MFMA tiles (16 accumulators), so one
+// operand register feeds four MFMAs: 8 LDS reads per 16 MFMAs, and a panel byte loaded from memory serves 128 rows of
+// the other panel -- half the memory traffic per flop of the 64 x 64 tiles of round 2, whose 2 x 2 quadrants waited on
+// their loads (35-46 % of the matrix peak).  74 KB of LDS: two workgroups per CU.
+// grid (tiles on or above the diagonal, ksplit); partial[ks][P128][P128].
 // ------------------------------------------------------------------------------------------------
-constexpr int kCovBM = 64, kCovBK = 32, kCovLd = kCovBK + 2;
+constexpr int kCovBM = 128, kCovBK = 16, kCovLd = kCovBK + 2;
 
 template <bool EVEN>     // EVEN: M even and X 16-byte aligned, so every row takes 16-byte loads
-__global__ __launch_bounds__(256) void k_cov_mfma(const double* __restrict__ X, const double* __restrict__ mean, i64 M,
-                                                  i64 P, int nb, i64 kchunk, double* __restrict__ partial)
+__global__ __launch_bounds__(256, 2) void k_cov_mfma(const double* __restrict__ X, const double* __restrict__ mean, i64 M,
+                                                     i64 P, int nb, i64 kchunk, double* __restrict__ partial)
 {
     typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) double sA[2][kCovBM * kCovLd];
     __shared__ __attribute__((aligned(16))) double sB[2][kCovBM * kCovLd];
-    const int bi = blockIdx.x / nb, bj = blockIdx.x % nb;
-    if (bj < bi) return;
+    // upper-triangle tile index -> (bi, bj), bi <= bj: row bi holds nb - bi tiles
+    int bi = 0, rest = (int)blockIdx.x;
+    while (rest >= nb - bi) { rest -= nb - bi; ++bi; }
+    const int bj = bi + rest;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ks = blockIdx.y;
     const i64 t0 = (i64)ks * kchunk, t1 = (t0 + kchunk < M) ? t0 + kchunk : M;
 
-    // staging role of this lane: rows lr + 16 u (u = 0..3) of both panels, draws 2 lc, 2 lc + 1 of the step
-    const int lr = tid >> 4, lc = tid & 15;
-    const double* pa[4]; const double* pb[4];
-    double ma[4], mb[4];
-    bool va[4], vb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const i64 ra = (i64)bi * kCovBM + lr + 16 * u, rb = (i64)bj * kCovBM + lr + 16 * u;
-        va[u] = ra < P; vb[u] = rb < P;
-        pa[u] = X + (va[u] ? ra : 0) * M; pb[u] = X + (vb[u] ? rb : 0) * M;
-        ma[u] = va[u] ? mean[ra] : 0.0; mb[u] = vb[u] ? mean[rb] : 0.0;
-    }
-    double ra_[4][2], rb_[4][2];
-    // Loads are unconditional (addresses clamped into the row, invalid rows read row 0) and masked afterwards: no
-    // branch sits between a load and the next one, so all 8 of a step are in flight together -- and they stay in
-    // flight during the MFMAs of the current panel: `fetch` only issues them, `stash` (after the MFMAs) centres, masks
-    // and writes them to the other LDS buffer.
-    bool in0 = false, in1 = false;
+    // staging role of this lane: row lr of both panels, draws 8 lh .. 8 lh + 7 of the step
+    const int lr = tid >> 1, lh = tid & 1;
+    const i64 rowa = (i64)bi * kCovBM + lr, rowb = (i64)bj * kCovBM + lr;
+    const bool va = rowa < P, vb = rowb < P;
+    const double* pa = X + (va ? rowa : 0) * M;
+    const double* pb = X + (vb ? rowb : 0) * M;
+    const double ma = va ? mean[rowa] : 0.0, mb = vb ? mean[rowb] : 0.0;
+    double ra[8], rb[8];
+    i64 cur = 0;
+    // Loads are unconditional (addresses clamped into the row, invalid rows read row 0) and masked afterwards: no branch
+    // sits between a load and the next one, so all 8 of a step are in flight together -- and they stay in flight during
+    // the MFMAs of the current panel: `fetch` only issues them, `stash` (after the MFMAs) centres, masks and writes them to
+    // the other LDS buffer.
     auto fetch = [&](i64 t) {
-        const i64 c = t + 2 * lc;
-        in0 = c < t1; in1 = c + 1 < t1;
+        cur = t + 8 * lh;
         if constexpr (EVEN) {
-            const i64 cc = (c + 1 < M) ? c : M - 2;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double2 v = *reinterpret_cast<const double2*>(pa[u] + cc); ra_[u][0] = v.x; ra_[u][1] = v.y; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const double2 v = *reinterpret_cast<const double2*>(pb[u] + cc); rb_[u][0] = v.x; rb_[u][1] = v.y; }
+            for (int u = 0; u < 4; ++u) {
+                const i64 c = cur + 2 * u, cc = (c + 1 < M) ? c : M - 2;
+                const double2 x = *reinterpret_cast<const double2*>(pa + cc), y = *reinterpret_cast<const double2*>(pb + cc);
+                ra[2 * u] = x.x; ra[2 * u + 1] = x.y; rb[2 * u] = y.x; rb[2 * u + 1] = y.y;
+            }
         } else {
-            const i64 c0 = (c < M) ? c : M - 1, c1 = (c + 1 < M) ? c + 1 : M - 1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { ra_[u][0] = pa[u][c0]; ra_[u][1] = pa[u][c1]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { rb_[u][0] = pb[u][c0]; rb_[u][1] = pb[u][c1]; }
+            for (int u = 0; u < 8; ++u) { const i64 c = (cur + u < M) ? cur + u : M - 1; ra[u] = pa[c]; rb[u] = pb[c]; }
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the uses of these registers behind the MFMAs that follow
     };
     auto stash = [&](int buf) {
         __builtin_amdgcn_sched_barrier(0);
+        double xa[8], xb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = cur + u < t1;
+            xa[u] = (va && in) ? ra[u] - ma : 0.0;
+            xb[u] = (vb && in) ? rb[u] - mb : 0.0;
+        }
+        const int o = lr * kCovLd + 8 * lh;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int o = (lr + 16 * u) * kCovLd + 2 * lc;
-            *reinterpret_cast<double2*>(&sA[buf][o]) = make_double2((va[u] && in0) ? ra_[u][0] - ma[u] : 0.0,
-                                                                    (va[u] && in1) ? ra_[u][1] - ma[u] : 0.0);
-            *reinterpret_cast<double2*>(&sB[buf][o]) = make_double2((vb[u] && in0) ? rb_[u][0] - mb[u] : 0.0,
-                                                                    (vb[u] && in1) ? rb_[u][1] - mb[u] : 0.0);
+            *reinterpret_cast<double2*>(&sA[buf][o + 2 * u]) = make_double2(xa[2 * u], xa[2 * u + 1]);
+            *reinterpret_cast<double2*>(&sB[buf][o + 2 * u]) = make_double2(xb[2 * u], xb[2 * u + 1]);
         }
     };
 
-    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;        // this wave's quadrant
+    const int wr = (w >> 1) * 64, wc = (w & 1) * 64;        // this wave's quadrant
     const int oi = lane & 15, ok = lane >> 4;                 // operand row / draw of this lane
-    v4d acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = v4d{0, 0, 0, 0};
     int buf = 0;
     if (t0 < t1) { fetch(t0); stash(0); }
     __syncthreads();
@@ -196,28 +201,28 @@ __global__ __launch_bounds__(256) void k_cov_mfma(const double* __restrict__ X, 
 #pragma unroll
         for (int kk = 0; kk < kCovBK / 4; ++kk) {
             const int c = kk * 4 + ok;
-            const double a0 = A[(wr + oi) * kCovLd + c], a1 = A[(wr + 16 + oi) * kCovLd + c];
-            const double b0 = B[(wc + oi) * kCovLd + c], b1 = B[(wc + 16 + oi) * kCovLd + c];
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = A[(wr + 16 * a + oi) * kCovLd + c]; bv[a] = B[(wc + 16 * a + oi) * kCovLd + c]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
     // result layout measured on gfx950 (tools/ubench/mfma64_layout.hip): D[(lane/16) + 4*v][lane%16] = acc[v]
-    const i64 P64 = (i64)nb * kCovBM;
-    double* out = partial + (i64)ks * P64 * P64;
+    const i64 PB = (i64)nb * kCovBM;
+    double* out = partial + (i64)ks * PB * PB;
     const i64 r0 = (i64)bi * kCovBM + wr + ok, c0 = (i64)bj * kCovBM + wc + oi;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        out[(r0 + 4 * v) * P64 + c0] = acc00[v];
-        out[(r0 + 4 * v) * P64 + c0 + 16] = acc01[v];
-        out[(r0 + 16 + 4 * v) * P64 + c0] = acc10[v];
-        out[(r0 + 16 + 4 * v) * P64 + c0 + 16] = acc11[v];
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) out[(r0 + 16 * a + 4 * v) * PB + c0 + 16 * b] = acc[a][b][v];
 }
 
 // cov[i][j] = sum over draw slices of G[min(i,j)-block-ordered entry] / M (only tiles on or above the diagonal exist).
@@ -227,9 +232,9 @@ __global__ void k_cov_final(const double* __restrict__ partial, int ksplit, int 
     if (idx >= P * P) return;
     i64 i = idx / P, j = idx % P;
     if (j / kCovBM < i / kCovBM) { const i64 t = i; i = j; j = t; }       // below the block diagonal: read the mirrored entry
-    const i64 P64 = (i64)nb * kCovBM;
+    const i64 PB = (i64)nb * kCovBM;
     double g = 0.0;
-    for (int ks = 0; ks < ksplit; ++ks) g += partial[(i64)ks * P64 * P64 + i * P64 + j];
+    for (int ks = 0; ks < ksplit; ++ks) g += partial[(i64)ks * PB * PB + i * PB + j];
     cov[idx] = g / (double)M;
 }
 

@@ -3,9 +3,12 @@
 
     python tools/cov_bench.py [--out gpurun_out/cov.json]
 
-FLOPs counted = 2 * P^2 * M (the full Gram matrix a dense SYRK is priced at); the kernel computes only the block
-upper triangle, so `useful_fraction` says how much of that count it really executes.  Peak: 78.6 TFLOP/s
-(256 CUs x 4 SIMDs x 32 fp64 FMA per clock x 2.4 GHz; MI355X spec fp64 matrix = fp64 vector rate).
+`executed_*` counts the flops the kernel really executes: 2 * M * 128 * 128 per tile on or above the block diagonal
+(`frac_of_peak` is on those).  `priced_*` counts 2 * P^2 * M, the full Gram matrix a dense SYRK is priced at, of which the
+upper-triangle tiling executes about half -- kept for comparison with round 2, never as the utilisation.  Peak: 78.6
+TFLOP/s (256 CUs x 4 SIMDs x 32 fp64 FMA per clock x 2.4 GHz; MI355X spec fp64 matrix = fp64 vector rate); a bare loop of
+independent `v_mfma_f64_16x16x4f64` reaches 46.1 TFLOP/s on this chip (tools/ubench/mfma64_rate.hip,
+profiles/r03_mfma64_rate.txt): `frac_of_instruction_peak` is against that.
 Parity unpinned by the reference (no covariance there): the result is checked against numpy.cov(ddof=0)."""
 import argparse, json, sys, time
 from pathlib import Path
@@ -15,6 +18,8 @@ sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
 from mcmc_ref_hip import _ffi
 
 PEAK_TF = 78.6
+MFMA_LOOP_TF = 46.1      # measured: tools/ubench/mfma64_rate, 5 independent accumulators, every CU busy
+TILE = 128
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=None)
 ap.add_argument("--reps", type=int, default=5)
@@ -38,15 +43,19 @@ for P, M in ((100, 40000), (1000, 40000), (2048, 40000), (4096, 20000)):
     wall = (time.perf_counter() - t0) / a.reps
     pr = ctx.profile_get(); ctx.profile(False)
     kms = pr["k_cov_mfma"]["total_ms"] / pr["k_cov_mfma"]["launches"]
-    nb = (P + 63) // 64
-    flops = 2.0 * P * P * M
-    rows.append({"P": P, "M": M, "kernel_ms": kms, "call_ms": wall * 1e3, "TFLOPs": flops / (kms * 1e-3) / 1e12,
-                 "frac_of_peak": flops / (kms * 1e-3) / 1e12 / PEAK_TF,
-                 "useful_fraction": (nb * (nb + 1) / 2 * 64 * 64) / float(P * P), "max_rel_err_vs_numpy": err,
+    nb = (P + TILE - 1) // TILE
+    priced = 2.0 * P * P * M
+    executed = 2.0 * M * (nb * (nb + 1) / 2) * TILE * TILE
+    ex_tf = executed / (kms * 1e-3) / 1e12
+    rows.append({"P": P, "M": M, "kernel_ms": kms, "call_ms": wall * 1e3,
+                 "executed_TFLOPs": ex_tf, "frac_of_peak": ex_tf / PEAK_TF, "frac_of_instruction_peak": ex_tf / MFMA_LOOP_TF,
+                 "priced_TFLOPs": priced / (kms * 1e-3) / 1e12, "priced_frac_of_peak": priced / (kms * 1e-3) / 1e12 / PEAK_TF,
+                 "executed_over_priced": executed / priced, "max_rel_err_vs_numpy": err,
                  "other_kernels_ms": {k: v["total_ms"] / v["launches"] for k, v in pr.items() if k != "k_cov_mfma"}})
     print(json.dumps(rows[-1]), flush=True)
     dx.free(); dc.free()
-out = {"kernel": "k_cov_mfma (v_mfma_f64_16x16x4f64, 64x64 tiles, LDS-staged, double-buffered)", "peak_TFLOPs": PEAK_TF, "rows": rows}
+out = {"kernel": "k_cov_mfma (v_mfma_f64_16x16x4f64, 128x128 tiles = 4x4 MFMA tiles per wave, LDS-staged, double-buffered)",
+       "peak_TFLOPs": PEAK_TF, "mfma_f64_16x16x4_loop_TFLOPs_measured": MFMA_LOOP_TF, "rows": rows}
 if a.out:
     Path(a.out).write_text(json.dumps(out, indent=1) + "\n")
 ctx.close()
