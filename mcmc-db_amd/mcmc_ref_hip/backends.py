@@ -35,18 +35,28 @@ class BackendSpec:
     loader: Callable[[], Backend]
 
 
-def columns_to_matrix(table: Any, params: list[str]) -> np.ndarray:
-    """[P][M] float64 matrix of the requested columns (Arrow Table, reader, or mapping of arrays)."""
+def columns_as_arrays(table: Any, params: list[str]) -> list[np.ndarray]:
+    """The requested columns as float64 arrays (Arrow Table, reader, or mapping of arrays).  Arrow nulls are DROPPED, as
+    `pc.mean` / `pc.stddev` / `pc.quantile(skip_nulls=True)` do in ArrowBackend.stats (src/mcmc_ref/backends_arrow.py:38-42),
+    so the columns may come back with different lengths."""
     if hasattr(table, "read_all"):
         table = table.read_all()
     cols = []
     for p in params:
         if hasattr(table, "column"):
             col = table.column(p)              # KeyError from pyarrow for unknown columns, as in the reference
+            if getattr(col, "null_count", 0):
+                col = col.drop_null()
             arr = col.to_numpy(zero_copy_only=False) if hasattr(col, "to_numpy") else np.asarray(col)
         else:
             arr = np.asarray(table[p])
         cols.append(np.asarray(arr, dtype=np.float64).reshape(-1))
+    return cols
+
+
+def columns_to_matrix(table: Any, params: list[str]) -> np.ndarray:
+    """[P][M] float64 matrix of the requested columns; all of them must have the same length once nulls are dropped."""
+    cols = columns_as_arrays(table, params)
     if not cols:
         return np.empty((0, 0), dtype=np.float64)
     m = len(cols[0])
@@ -64,7 +74,9 @@ class HipBackend:
     Same contract as ArrowBackend.stats / NumpyBackend.stats (src/mcmc_ref/backends_arrow.py:22-52,
     backends_numpy.py:17-49): pooled mean, population std, linear-interpolated quantiles under the
     keys f"q{int(q*100)}".  `quantile_mode` is accepted and ignored, as in the reference.
-    Null / NaN draws are rejected with ValueError instead of being skipped.
+    Arrow nulls are skipped like ArrowBackend does (backends_arrow.py:38-42: columns that keep different numbers of
+    draws go through the kernels in groups of equal length); a column with no draw left raises ValueError, and so do
+    NaN / infinite draws (the reference's two backends disagree on them; the kernels reject them).
     """
 
     name = "hip"
@@ -86,23 +98,29 @@ class HipBackend:
         from . import _ffi
         params = list(params)
         qs = list(quantiles)
-        x = columns_to_matrix(table, params)
+        cols = columns_as_arrays(table, params)
         if not params:
             return {}
-        P, M = x.shape
-        if M == 0:
+        if any(len(c) == 0 for c in cols):
             raise ValueError("cannot compute stats of empty columns")
-        try:
-            r = self._ctx.summarize(x.reshape(P, 1, M), "pcn", min_chains=1, quantiles=qs, diagnostics=False)
-        except _ffi.McrError as exc:
-            raise ValueError(exc.message) from exc
-        results: dict[str, dict[str, float]] = {}
-        for i, param in enumerate(params):
-            entry = {"mean": float(r["mean"][i]), "std": float(r["std"][i])}
-            for q, v in zip(qs, r["q"][i], strict=False):
-                entry[f"q{int(q * 100)}"] = float(v)
-            results[param] = entry
-        return results
+        by_len: dict[int, list[int]] = {}
+        for i, c in enumerate(cols):
+            by_len.setdefault(len(c), []).append(i)
+        entries: dict[int, dict[str, float]] = {}
+        for M, members in by_len.items():          # one group unless nulls were dropped unevenly
+            x = np.empty((len(members), 1, M), dtype=np.float64)
+            for k, i in enumerate(members):
+                x[k, 0] = cols[i]
+            try:
+                r = self._ctx.summarize(x, "pcn", min_chains=1, quantiles=qs, diagnostics=False)
+            except _ffi.McrError as exc:
+                raise ValueError(exc.message) from exc
+            for k, i in enumerate(members):
+                entry = {"mean": float(r["mean"][k]), "std": float(r["std"][k])}
+                for q, v in zip(qs, r["q"][k], strict=False):
+                    entry[f"q{int(q * 100)}"] = float(v)
+                entries[i] = entry
+        return {param: entries[i] for i, param in enumerate(params)}
 
 
 def _load_hip() -> Backend:

@@ -231,12 +231,17 @@ def convert_files(jobs, out_draws_dir: Path, out_meta_dir: Path, force: bool = F
     ctx = None
     if any(v[1] for v in prepared.values()):
         ctx = context or _ffi.default_context()
-    window: list[tuple[int, object]] = []
+    window: list[tuple[int, object, object]] = []          # (job, device tensor, the result buffers enqueue() handed back)
+    if ctx is not None and ctx.inflight:
+        ctx.wait()       # somebody else's calls on this context: wait_one() below must deliver OUR oldest call, nobody else's
 
     def retire():
-        i, t = window.pop(0)
+        i, t, mine = window.pop(0)
         try:
-            r = ctx.wait_one().result()
+            got = ctx.wait_one()
+            if got is not mine:        # cannot happen on a context drained above; never hand a model another call's numbers
+                raise RuntimeError("convert_files: the context delivered a result that is not this model's")
+            r = got.result()
             diags[i] = {p: {"rhat": float(r["rhat"][k]), "ess_bulk": float(r["ess_bulk"][k]),
                             "ess_tail": float(r["ess_tail"][k])} for k, p in enumerate(prepared[i][1])}
         except _ffi.McrError as exc:
@@ -245,27 +250,39 @@ def convert_files(jobs, out_draws_dir: Path, out_meta_dir: Path, force: bool = F
             t.free()
 
     ragged = []
-    for i, (table, params, n_chains, n_draws, x, counts) in prepared.items():
-        if not params:
-            diags[i] = {}
-            continue
-        if not np.all(counts == counts[0]):
-            ragged.append(i)
-            continue
-        if len(window) == _ffi.MCR_MAX_INFLIGHT:
-            retire()
-        try:
-            t = ctx.upload(x.reshape(len(params), len(counts), int(counts[0])), "pcn")
+    try:
+        for i, (table, params, n_chains, n_draws, x, counts) in prepared.items():
+            if not params:
+                diags[i] = {}
+                continue
+            if not np.all(counts == counts[0]):
+                ragged.append(i)
+                continue
+            if len(window) == _ffi.MCR_MAX_INFLIGHT:
+                retire()
             try:
-                ctx.enqueue(t, min_chains=min_chains, quantiles=())
-            except Exception:
+                t = ctx.upload(x.reshape(len(params), len(counts), int(counts[0])), "pcn")
+                try:
+                    bufs = ctx.enqueue(t, min_chains=min_chains, quantiles=())
+                except Exception:
+                    t.free()
+                    raise
+                window.append((i, t, bufs))
+            except _ffi.McrError as exc:
+                results[i] = ValueError(exc.message)
+        while window:
+            retire()
+    finally:
+        # anything but a kernel-side failure of one model (handled above) ends the batch: nothing stays in flight and no
+        # device tensor stays allocated behind the exception
+        if window:
+            try:
+                ctx.wait()
+            except Exception:  # noqa: BLE001 - the original exception is the one to report
+                pass
+            for _i, t, _b in window:
                 t.free()
-                raise
-            window.append((i, t))
-        except _ffi.McrError as exc:
-            results[i] = ValueError(exc.message)
-    while window:
-        retire()
+            window.clear()
     for i in ragged:                                  # chains of unequal length: one pipeline per parameter
         table, params = prepared[i][:2]
         try:

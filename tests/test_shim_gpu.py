@@ -140,8 +140,22 @@ def test_hip_backend_agrees_with_arrow_and_numpy():
     assert st["v"] == pytest.approx(qg["numpy"]["v"], rel=1e-12)
     for q in qg["quantiles"]:
         assert st["v"][f"q{int(q * 100)}"] == qg["numpy"]["v"][f"q{int(q * 100)}"]      # bit-exact
+    # nulls are skipped, as ArrowBackend.stats does (backends_arrow.py:38-42: pc.mean / pc.stddev / quantile(skip_nulls=True));
+    # expected values from pyarrow itself on the same table, columns of different surviving lengths in one call
+    import pyarrow.compute as pc
+    tn = pa.table({"v": pa.array([1.0, None, 2.0, 4.5, None, -3.0]), "w": pa.array([0.5, 1.5, None, 2.5, 3.5, 9.0]),
+                   "u": pa.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])})
+    got = be.stats(tn, ["v", "w", "u"])
+    for name in ("v", "w", "u"):
+        col = tn.column(name)
+        assert got[name]["mean"] == pytest.approx(pc.mean(col).as_py(), rel=1e-14)
+        assert got[name]["std"] == pytest.approx(pc.stddev(col).as_py(), rel=1e-14)
+        qv = pc.quantile(col, q=[0.05, 0.5, 0.95], interpolation="linear", skip_nulls=True).to_pylist()
+        assert [got[name]["q5"], got[name]["q50"], got[name]["q95"]] == pytest.approx(qv, rel=1e-14)
     with pytest.raises(ValueError):
-        be.stats(pa.table({"v": pa.array([1.0, None, 2.0])}), ["v"])                   # nulls are rejected
+        be.stats(pa.table({"v": pa.array([None, None], type=pa.float64())}), ["v"])     # nothing left
+    with pytest.raises(ValueError):
+        be.stats(pa.table({"v": pa.array([1.0, float("nan"), 2.0])}), ["v"])           # NaN is a value, and rejected
 
 
 # ---- convert._compute_diagnostics on Arrow tables (the provenance-generate call site) ----------

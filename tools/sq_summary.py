@@ -4,7 +4,16 @@
     python tools/sq_summary.py pass_a.csv [pass_b.csv ...] > profiles/r02_sq_summary.json
 
 SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md):
-WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES."""
+WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES.
+
+Utilisation is normalised by the counters themselves, not by the nominal residency (What's weak 2):
+  simd_quad_cycles   = SQ_BUSY_CYCLES / 32 (the counter is summed over the 32 shader engines) / 4 * 1024 SIMDs
+  avg_resident_waves = SQ_WAVE_CYCLES / simd_quad_cycles          (per SIMD, over the kernel's busy time)
+  valu_issue_share   = SQ_INSTS_VALU / simd_quad_cycles           (1.0 = one VALU instruction per SIMD every 4 cycles,
+                       which is what ONE wave can issue; the SIMD-32 pipe itself takes a 32-bit instruction every 2
+                       cycles when two or more waves have one ready, so 2.0 would be its ceiling for 32-bit work)
+  kernel_us_at_2p4GHz = SQ_BUSY_CYCLES / 32 / 2400"""
+N_SE, N_SIMD = 32, 1024
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -47,5 +56,14 @@ for k in sorted(tot):
             r["lds_bank_conflict_cycles_per_lds_inst"] = round(a["SQ_LDS_BANK_CONFLICT"] / a["SQ_INSTS_LDS"], 3)
         if "SQ_LDS_IDX_ACTIVE" in a:
             r["lds_array_cycles_per_lds_inst"] = round(a["SQ_LDS_IDX_ACTIVE"] / a["SQ_INSTS_LDS"], 3)
+    if a.get("SQ_BUSY_CYCLES"):
+        sqc = a["SQ_BUSY_CYCLES"] / N_SE / 4.0 * N_SIMD
+        r["kernel_us_at_2p4GHz"] = round(a["SQ_BUSY_CYCLES"] / N_SE / 2400.0, 2)
+        if wc:
+            r["avg_resident_waves_per_simd"] = round(wc / sqc, 3)
+        if "SQ_INSTS_VALU" in a:
+            r["valu_issue_share_of_simd_quad_cycles"] = round(a["SQ_INSTS_VALU"] / sqc, 3)
+        if "SQ_INSTS_LDS" in a:
+            r["lds_insts_per_simd_quad_cycle"] = round(a["SQ_INSTS_LDS"] / sqc, 4)
     out[k] = {"per_launch": {c: round(v, 1) for c, v in sorted(a.items())}, "ratios": r}
 print(json.dumps(out, indent=1))
