@@ -432,13 +432,14 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
                (const unsigned*)a.more, a.rec2);
     }
+    const bool fused_tier3 = !a.fft.on && a.n <= 16384 && 2 * a.pc <= kTier3MaxPairs;     // k_tier3: one launch for the whole tier
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
            (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB,   // kA / kB: the sort's key buffers, free by now
-           (const double*)a.part, (int)a.ntiles);
+           (const double*)a.part, (int)a.ntiles, fused_tier3 ? 0 : 1);
     if (a.n <= kLag2) return MCR_OK;       // chains short enough to be decided by lag 255 never reach tier 3
-    if (!a.fft.on && a.n <= 16384 && 2 * a.pc <= kTier3MaxPairs) {
+    if (fused_tier3) {
         // the common case in one launch: list, products of the single round [256, n) and scan (k_tier3)
         const unsigned groups = (unsigned)((a.n - kLag2 + kLongGroup - 1) / kLongGroup);
         const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
@@ -448,6 +449,12 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     }
     LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
            a.long_count, a.long_list);
+    {
+        const unsigned slots = (unsigned)((2 * a.pc < 64) ? 2 * a.pc : 64);
+        LAUNCH(ctx, K_DIAG2, k_dev_fill, dim3((unsigned)((a.M + 4095) / 4096), slots), dim3(256), 0, (const u32*)a.zb, (const u32*)a.zt,
+               (const double*)a.ztab, a.M, a.d_off, a.C, a.n, (const double*)a.chstate, (const unsigned*)a.long_count,
+               (const unsigned*)a.long_list, a.kA, a.kB);
+    }
     // tier 3 for the pairs still undecided at lag 256.
     //  * chains of more than 16 384 draws: ALL lags of the first fft.slots listed pairs by FFT (mcr_fft.hpp);
     //  * everything else (and list entries beyond those slots): direct products over the whole chip, in rounds

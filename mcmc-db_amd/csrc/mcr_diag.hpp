@@ -451,7 +451,7 @@ __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const 
                                               const double* __restrict__ chstate,
                                               double* __restrict__ res, i64 P,
                                               double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                              double* hb, double (*wcov)[64], double* ctl)
+                                              double* hb, double (*wcov)[64], double* ctl, bool defer_dev)
 {
     constexpr int NW2 = 16;
     const i64 p = blockIdx.x;
@@ -524,8 +524,10 @@ __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const 
         return;
     }
     // ---- still undecided at lag kLag2: hand the pair to tier 3 ----
+    // (long chains: the deviations are written by k_dev_fill, chip-wide, once the list exists -- one workgroup walking
+    //  C x n dependent table reads took 0.6 ms per pair at n = 100 000)
     double* dev = (kind ? dev_t : dev_b) + p * M;
-    for (int c = 0; c < C; ++c) {
+    for (int c = 0; c < C && !defer_dev; ++c) {
         const double* cs = chstate + (pk * C + c) * kChState;
         const bool konst = cs[2] != 0.0;
         const double m = cs[0];
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
                                                        const double* __restrict__ chstate,
                                                        double* __restrict__ res, i64 P,
                                                        double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                                       const double* __restrict__ part, int ntiles)
+                                                       const double* __restrict__ part, int ntiles, int defer_dev)
 {
     __shared__ double ctl[3];
     __shared__ double wcov[16][64];
@@ -558,7 +560,29 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
     // k_finalize, done here by the first thread of the parameter's first workgroup
     if (blockIdx.y == 0 && tid == 0) finalize_param(part, ntiles, M, P, C, res, blockIdx.x);
     combine2_pair(zb, zt, ztab, M, off, C, n, nseg, rec2, more, state, chstate, res, P, dev_b, dev_t,
-                  reinterpret_cast<double*>(smem2), wcov, ctl);
+                  reinterpret_cast<double*>(smem2), wcov, ctl, defer_dev != 0);
+}
+
+// Deviations z - mean of the listed pairs, in time order, for tier 3: grid (chunks of 4096 pooled draws, slots), block 256.
+__global__ __launch_bounds__(256) void k_dev_fill(const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                  const double* __restrict__ ztab, i64 M, const i64* __restrict__ off, int C,
+                                                  i64 n, const double* __restrict__ chstate,
+                                                  const unsigned* __restrict__ long_count, const unsigned* __restrict__ long_list,
+                                                  double* __restrict__ dev_b, double* __restrict__ dev_t)
+{
+    const unsigned count = *long_count;
+    const i64 j0 = (i64)blockIdx.x * 4096;
+    for (unsigned slot = blockIdx.y; slot < count; slot += gridDim.y) {
+        const i64 pk = long_list[slot], p = pk >> 1;
+        const u32* z = ((pk & 1) ? zt : zb) + p * M;
+        double* dev = ((pk & 1) ? dev_t : dev_b) + p * M;
+        for (i64 j = j0 + threadIdx.x; j < j0 + 4096 && j < M; j += 256) {
+            int lo = 0, hi = C;                          // chain of pooled position j: last c with off[c] <= j
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= j) lo = mid; else hi = mid; }
+            const double* cs = chstate + (pk * C + lo) * kChState;
+            if (j - off[lo] < n) dev[j] = (cs[2] != 0.0) ? 0.0 : zdec(ztab, z[j], M) - cs[0];
+        }
+    }
 }
 
 // The tier-3 list in ascending pair order: one workgroup compacts the marks of all 2 P pairs.  grid 1, block 1024.
