@@ -482,6 +482,7 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
         slot_from = F;
     }
     const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
+    const unsigned scan_slots = (unsigned)((2 * a.pc < 16) ? 2 * a.pc : 16);      // one light workgroup per listed pair at a time
     for (i64 L0 = kLag2; L0 < a.n;) {
         const i64 L1 = (L0 < 16384) ? 16384 : L0 * 4;
         const i64 lend = (L1 < a.n) ? L1 : a.n;
@@ -489,7 +490,7 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
         LAUNCH(ctx, K_ACOV_LONG, (k_acov_long<256>), dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB,
                a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
                (const double*)a.state, a.acov, slot_from);
-        LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
+        LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(scan_slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
                (const unsigned*)a.long_list, a.state, a.acov, a.d_res, a.pc, (const double*)a.kA, (const double*)a.kB, a.M,
                a.d_off, ctx->rho_band, ctx->guard_count);
         L0 = L1;

@@ -713,6 +713,7 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
     const double vhat = stp[2];
     double* a = acov + pk * n;
     const double den = (double)C * vhat;
+    const double thr = band * den;
     i64 from = L0, first = lend;
     int budget = kGuardMax;
     for (;;) {
@@ -720,8 +721,9 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
         __syncthreads();
         long long mine = (long long)lend;
         for (i64 l = from + tid; l < lend; l += 256) {
-            const double rho = (a[l] / (double)(n - l)) / den;
-            if (rho < band) { mine = l; break; }                   // the thread's lags ascend: its first one below the band's top
+            // rho < band  <=>  acov < band * den * (n - l) (den > 0): no division in the search; where exactly the band's
+            // top lies does not matter, every lag it catches is looked at again below
+            if (a[l] < thr * (double)(n - l)) { mine = l; break; }     // the thread's lags ascend: its first one below the band's top
         }
         if (mine < (long long)lend) atomicMin(&S.sfirst, mine);
         __syncthreads();

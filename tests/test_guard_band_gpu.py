@@ -99,3 +99,30 @@ def test_tier3_list_order_is_a_function_of_the_data(ctx):
                 assert np.array_equal(first[k], again[k]), k
     finally:
         t.free()
+
+
+def test_tier3_single_launch_and_listed_routes_agree_with_the_oracle(ctx, oracle):
+    """Chains of at most 16 384 draws take tier 3 in ONE launch (k_tier3: the list compacted into every workgroup's LDS,
+    256-lag groups, the pair's last group runs the scan) when a chunk holds at most 2 048 pairs, and the listed route
+    (k_long_list + k_dev_fill + k_acov_long + k_diag_long_scan) beyond that.  Random walks put many pairs on the list --
+    more than the two slots of a launch -- with truncation lags on both sides of 256."""
+    rng = np.random.default_rng(21)
+    x = np.cumsum(rng.normal(size=(12, 4, 6000)), axis=2) * 0.01            # 24 pairs, k_tier3
+    x[3] = rng.normal(size=(4, 6000))
+    exp = oracle.summarize(x, "pcn")
+    got = ctx.summarize(x, "pcn")
+    lags = np.concatenate([exp["lag_bulk"], exp["lag_tail"]])
+    assert (lags > 256).sum() >= 12 and (lags < 64).sum() >= 2
+    for k in ("lag_bulk", "lag_tail"):
+        assert np.array_equal(got[k], exp[k]), k
+    for k in ("ess_bulk", "ess_tail", "rhat"):
+        assert np.allclose(got[k], exp[k], rtol=1e-9, atol=0), k
+    y = np.cumsum(rng.normal(size=(1030, 4, 1200)), axis=2) * 0.01          # 2 060 pairs in one chunk: the listed route
+    expy = oracle.summarize(y, "pcn")
+    goty = ctx.summarize(y, "pcn")
+    ly = np.concatenate([expy["lag_bulk"], expy["lag_tail"]])
+    assert (ly > 256).sum() >= 100
+    for k in ("lag_bulk", "lag_tail"):
+        assert np.array_equal(goty[k], expy[k]), k
+    for k in ("ess_bulk", "ess_tail", "rhat"):
+        assert np.allclose(goty[k], expy[k], rtol=1e-9, atol=0), k
