@@ -992,13 +992,16 @@ __global__ __launch_bounds__(NT) void k_bucket_merge(const double* __restrict__ 
     __syncthreads();
     // merge rounds over adjacent runs (run boundaries = sst[] at stride 2^r)
     const int chunk0 = tid * VT;
+    int mypiece = 0;      // the piece that holds slot chunk0 (pieces are padded to 16 >= VT slots: a lane's chunk lies in one piece)
+#pragma unroll
+    for (int step = 8; step > 0; step >>= 1)
+        if (mypiece + step < k && chunk0 >= sst[mypiece + step]) mypiece += step;
     for (int w = 1; w < k; w <<= 1) {
         double kk[VT]; int srcs[VT]; u32 ix[VT];
         const bool active = chunk0 < padded;
         bool moved = false;
         if (active) {
-            int ra = 0;   // first piece of the pair that contains chunk0
-            while (ra + 2 * w < k && chunk0 >= sst[ra + 2 * w]) ra += 2 * w;
+            const int ra = mypiece & ~(2 * w - 1);   // first piece of the pair of runs (w pieces each) that contains chunk0
             const int a0 = sst[ra];
             const int a1 = sst[(ra + w < k) ? ra + w : k];
             const int b1 = sst[(ra + 2 * w < k) ? ra + 2 * w : k];

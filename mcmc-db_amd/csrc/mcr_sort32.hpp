@@ -327,12 +327,15 @@ __global__ __launch_bounds__(NT) void k_bucket_merge32(const u64* __restrict__ r
     }
     __syncthreads();
     const int chunk0 = tid * VT;
+    int mypiece = 0;      // the piece that holds slot chunk0 (pieces are padded to 16 >= VT slots)
+#pragma unroll
+    for (int step = 8; step > 0; step >>= 1)
+        if (mypiece + step < k && chunk0 >= sst[mypiece + step]) mypiece += step;
     for (int w = 1; w < k; w <<= 1) {
         u64 r[VT];
         bool moved = false;
         if (chunk0 < padded) {
-            int ra = 0;
-            while (ra + 2 * w < k && chunk0 >= sst[ra + 2 * w]) ra += 2 * w;
+            const int ra = mypiece & ~(2 * w - 1);
             const int a0 = sst[ra];
             const int a1 = sst[(ra + w < k) ? ra + w : k];
             const int b1 = sst[(ra + 2 * w < k) ? ra + 2 * w : k];

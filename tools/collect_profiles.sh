@@ -3,7 +3,8 @@
 # profiles/).  usage (through gpurun):  bash tools/collect_profiles.sh <tag>
 #   1. bench.py default run (the line the driver will reproduce)
 #   2. rocprofv3 --kernel-trace --stats of the same bench with MCR_LANES=1 (kernels alone, as the HIP-event pass times them)
-#   3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, counters only) -> per-kernel HBM traffic per launch
+#   3. rocprofv3 --kernel-trace --stats of the long-chain cases (tools/fft_prof.py: FFT tier, tier-3 kernels)
+#   4. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, counters only) -> per-kernel HBM traffic per launch
 set -u
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -28,5 +29,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_fetch_c1.csv" \;
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python3 $SHORT > /dev/null 2> /tmp/prof_w.err
 find /tmp/prof_w -name "*counter_collection.csv" -exec cp {} "$OUT/${TAG}_pmc_write_c1.csv" \;
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fft -o fft -- python3 $REPO/tools/fft_prof.py 20 > "$OUT/${TAG}_fft_prof.txt" 2> /tmp/prof_fft.err
+find /tmp/prof_fft -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_fft_kernel_stats.csv" \;
 cd "$REPO" && python tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch_c1.csv" "$OUT/${TAG}_pmc_write_c1.csv" > "$OUT/pmc_traffic.json"
 ls -la "$OUT"
