@@ -285,7 +285,7 @@ FftPlan plan_fft(i64 n, int C, bool enabled)
     const i64 N = (i64)1 << lg;
     i64 slots = ((i64)1 << 23) / N;
     f.slots = (int)(slots < 2 ? 2 : (slots > 32 ? 32 : slots));
-    f.cb = C < kFftChainBatch ? C : kFftChainBatch;
+    f.cb = (C + 1) / 2 < kFftChainBatch ? (C + 1) / 2 : kFftChainBatch;     // transforms per batch: two chains share one
     f.bytes = (size_t)f.slots * ((size_t)f.cb * N * 16 + (size_t)N * 8 + (size_t)N * 16) + 3 * 256;
     return f;
 }
@@ -465,10 +465,11 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
         const int N1 = 1 << pl.log1, N2 = 1 << pl.log2, cols = fft::kColElems >> pl.log1;
         const unsigned F = (unsigned)a.fft.slots;
         const size_t lds_cols = (size_t)fft::kColElems * 16, lds_rows = (size_t)N2 * 16;
-        for (int c0 = 0; c0 < a.C; c0 += a.fft.cb) {
-            const int nb = (a.C - c0 < a.fft.cb) ? a.C - c0 : a.fft.cb;
+        for (int c0 = 0; c0 < a.C; c0 += 2 * a.fft.cb) {          // a batch = fft.cb transforms = 2 fft.cb chains (two per transform)
+            const int left = (a.C - c0 + 1) / 2;
+            const int nb = (left < a.fft.cb) ? left : a.fft.cb;
             LAUNCH(ctx, K_FFT, (fft::k_fft_cols<256>), dim3((unsigned)(N2 / cols), (unsigned)nb, F), dim3(256), lds_cols,
-                   (const double*)a.kA, (const double*)a.kB, a.M, a.d_off, c0, a.n, pl, (const double2*)a.tw1,
+                   (const double*)a.kA, (const double*)a.kB, a.M, a.d_off, c0, a.C, a.n, pl, (const double2*)a.tw1,
                    (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state, a.fft_A, a.fft.cb);
             LAUNCH(ctx, K_FFT, (fft::k_fft_rows_power<256>), dim3((unsigned)N1, F), dim3(256), lds_rows, (const double2*)a.fft_A, pl,
                    (const double2*)a.tw2, (const unsigned*)a.long_count, (const unsigned*)a.long_list, (const double*)a.state,

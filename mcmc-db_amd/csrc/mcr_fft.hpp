@@ -10,6 +10,7 @@
 // rho_0) of zero, which the parity tests check on random walks against the CPU restatement of the reference.
 //
 // Layout (four-step, N = N1 x N2, both powers of two <= 2048, every sub-transform in LDS):
+// Two chains share one complex transform (real part: chain a, imaginary part: chain b; see k_fft_cols).
 //   FFT 1 (natural in, transposed out):  X[k1 + N1 k2] = sum_n2 W_N^(n2 k1) [sum_n1 x[n1 N2 + n2] W_N1^(n1 k1)] W_N2^(n2 k2)
 //     k_fft_cols : per tile of columns n2, length-N1 transforms over n1 (+ twiddle W_N^(n2 k1))  -> A[c][k1][n2]
 //     k_fft_rows_power : per row k1, length-N2 transforms over n2, |.|^2 summed over chains       -> S[k1][k2]
@@ -75,7 +76,7 @@ struct Plan { int log1, log2; };     // N1 = 2^log1, N2 = 2^log2, N = N1 N2
 // grid (N2 / COLS, chains of the batch, slots).  dev: deviations of the listed pair (chain c at off[c], n draws).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fft_cols(const double* __restrict__ dev_b, const double* __restrict__ dev_t, i64 M,
-                                                 const i64* __restrict__ off, int c0, i64 n, Plan pl,
+                                                 const i64* __restrict__ off, int c0, int C, i64 n, Plan pl,
                                                  const double2* __restrict__ tw1, const unsigned* __restrict__ long_count,
                                                  const unsigned* __restrict__ long_list, const double* __restrict__ state,
                                                  double2* __restrict__ A, int CB)
@@ -91,11 +92,17 @@ __global__ __launch_bounds__(NT) void k_fft_cols(const double* __restrict__ dev_
     {
         const i64 pk = long_list[slot];
         if (state[pk * kPairState + 3] != 0.0) return;
-        const double* dc = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M + off[c0 + cb];
+        // TWO chains per complex transform: z = d_a + i d_b.  |FFT z|^2 = |A|^2 + |B|^2 + (a real, ODD cross term), and the
+        // inverse transform of a real odd sequence is purely imaginary, so Re IFFT(|FFT z|^2) = acov_a + acov_b: the
+        // sum over chains that the spectrum is summed to anyway, at half the forward transforms and with no untangling.
+        const int ca = c0 + 2 * cb;
+        const double* dpair = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
+        const double* da = dpair + off[ca];
+        const double* db = (ca + 1 < C) ? dpair + off[ca + 1] : nullptr;
         for (int e = threadIdx.x; e < COLS * N1; e += NT) {
             const int n1 = e / COLS, cl = e - n1 * COLS;
             const i64 g = (i64)n1 * N2 + col0 + cl;
-            buf[(cl << pl.log1) + n1] = make_double2(g < n ? dc[g] : 0.0, 0.0);
+            buf[(cl << pl.log1) + n1] = make_double2(g < n ? da[g] : 0.0, (db != nullptr && g < n) ? db[g] : 0.0);
         }
         __syncthreads();
         lds_fft<NT>(buf, COLS, pl.log1, tw1);
