@@ -54,7 +54,7 @@ ALG_BYTES_PER_PD = {
 
 
 # profile_get() name -> name in profiles/pmc_traffic.json where they differ
-TRAFFIC_NAMES: dict[str, str] = {}
+TRAFFIC_NAMES: dict[str, str] = {"k_acov_long": "k_tier3"}      # the HIP-event label of tier 3 covers k_tier3 (chains up to 16 384 draws)
 
 
 def cpu_model() -> str:
@@ -528,7 +528,7 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
         for name, r in prof.items():
             avg_ms = r["total_ms"] / max(r["launches"], 1)
             alg = alg_bytes(name, es)
-            tb = ktraffic.get(TRAFFIC_NAMES.get(name, name))
+            tb = ktraffic.get(TRAFFIC_NAMES.get(name, name), ktraffic.get(name))
             kern[name] = {"launches_per_step": r["launches"] / a.steps, "avg_us": round(avg_ms * 1e3, 2),
                           "alg_GBps": round(alg * pd_step / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
                           # FETCH_SIZE + WRITE_SIZE of the kernel / its time.  The bytes are per launch from the
