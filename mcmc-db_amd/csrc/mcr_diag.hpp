@@ -42,13 +42,13 @@ constexpr int kSeg = 2048;      // draws of one chain per k_acov_seg workgroup (
 #define MCR_LAG1 64
 #endif
 constexpr int kLag1 = MCR_LAG1; // tier 1: lags 0 .. kLag1-1 (32 or 64: one lag per lane in k_diag_combine)
-constexpr int kSegRec = kLag1 + 8;   // doubles per tier-1 record: the lag products + 7 scalars
+constexpr int kSegRec = kLag1 + 12;  // doubles per tier-1 record: the lag products + 11 scalars
 constexpr int kMoreBlocks = 3;  // tier 2: lags 64 .. 64 + 64*3 - 1 = 255
 constexpr int kLag2 = kLag1 + 64 * kMoreBlocks;   // first lag of tier 3
 constexpr int kLongGroup = 256; // lags per k_acov_long workgroup
 constexpr int kLongSlots = 2;   // listed pairs a k_acov_long launch works on at a time (its grid: lag groups x this; a launch
                                 // with nothing listed must stay cheap: every workgroup of it still has to find a CU with free LDS)
-enum SegField { SG_S = kLag1, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX };
+enum SegField { SG_S = kLag1, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX, SG_MIN0, SG_MAX0, SG_MIN1, SG_MAX1 };   // (MIN / MAX of the rank codes: chain, first half, second half)
 
 __device__ __forceinline__ i64 pos8(i64 j) { return j + ((j >> 3) << 1); }
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     __shared__ __attribute__((aligned(16))) double sx[LX];
     __shared__ __attribute__((aligned(16))) double scr2[FIRST ? 8 : NW * 4 * 64];
     __shared__ double tot[64];
-    __shared__ double wred[NW * 4 * 8];
+    __shared__ double wred[NW * 4 * 12];
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         // they are taken on the integer codes (full-rate v_min_u32 / v_max_u32; the f64 pair is not, and needs its operands
         // canonicalised) and stored as doubles, which hold a u32 exactly
         u32 cmin = 0xFFFFFFFFu, cmax = 0u;
+        u32 c0min = 0xFFFFFFFFu, c0max = 0u, c1min = 0xFFFFFFFFu, c1max = 0u;    // the same for the two halves of the chain (split R-hat)
         double v[NLD];
         u32 cd[NLD];
 #pragma unroll
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
             const int jw = u * NT + jw0, j = u * NT + tid;
             const double x = v[u];
             MCR_IN_WINDOW(0, own_n, S += x; cmin = min(cmin, cd[u]); cmax = max(cmax, cd[u]);)
-            MCR_IN_WINDOW(a0, a1, S0 += x; Q0 = fma(x, x, Q0);)
-            MCR_IN_WINDOW(b0, b1, S1 += x; Q1 = fma(x, x, Q1);)
+            MCR_IN_WINDOW(a0, a1, S0 += x; Q0 = fma(x, x, Q0); c0min = min(c0min, cd[u]); c0max = max(c0max, cd[u]);)
+            MCR_IN_WINDOW(b0, b1, S1 += x; Q1 = fma(x, x, Q1); c1min = min(c1min, cd[u]); c1max = max(c1max, cd[u]);)
             if (j < WIN) sx[pos8(j)] = (j < r_n) ? x : 0.0;
         }
 #undef MCR_IN_WINDOW
@@ -230,19 +231,21 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         // lanes finish (one barrier; no cross-row shuffles).
         S = row_sum(S); S0 = row_sum(S0); Q0 = row_sum(Q0); S1 = row_sum(S1); Q1 = row_sum(Q1);
         cmin = row_min_u32(cmin); cmax = row_max_u32(cmax);
+        c0min = row_min_u32(c0min); c0max = row_max_u32(c0max); c1min = row_min_u32(c1min); c1max = row_max_u32(c1max);
         if ((tid & 15) == 0) {
-            double* q = wred + (tid >> 4) * 8;
+            double* q = wred + (tid >> 4) * 12;
             q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = (double)cmin; q[6] = (double)cmax;
+            q[7] = (double)c0min; q[8] = (double)c0max; q[9] = (double)c1min; q[10] = (double)c1max;
         }
         __syncthreads();
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;
-        if (tid < 7) {
+        if (tid < 11) {
             double t = wred[tid];
             for (int w = 1; w < NW * 4; ++w) {
-                const double x = wred[w * 8 + tid];
-                t = (tid < 5) ? t + x : ((tid == 5) ? fmin(t, x) : fmax(t, x));
+                const double x = wred[w * 12 + tid];
+                t = (tid < 5) ? t + x : (((tid & 1) == 1) ? fmin(t, x) : fmax(t, x));      // 5, 7, 9: minima; 6, 8, 10: maxima
             }
-            r[SG_S + tid] = t;        // SG_S, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX are consecutive
+            r[SG_S + tid] = t;        // SG_S, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX, SG_MIN0 .. SG_MAX1 are consecutive
         }
         double acc[8];
 #pragma unroll
@@ -318,14 +321,20 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     for (int c = w; c < C; c += W) {
         const double* R = rec + ((pk * C + c) * (i64)nseg) * kSegRec;
         double Pl = 0.0, S = 0.0, S0 = 0.0, Q0 = 0.0, S1 = 0.0, Q1 = 0.0, Q = 0.0;
-        double vmin = INFINITY, vmax = -INFINITY;
+        double vmin = INFINITY, vmax = -INFINITY, vmin0 = INFINITY, vmax0 = -INFINITY, vmin1 = INFINITY, vmax1 = -INFINITY;
         for (int sgm = 0; sgm < nseg; ++sgm) {
             const double* r = R + (i64)sgm * kSegRec;
             Pl += (lane < kLag1) ? r[lane] : 0.0; Q += r[0];
             S += r[SG_S]; S0 += r[SG_S0]; Q0 += r[SG_Q0]; S1 += r[SG_S1]; Q1 += r[SG_Q1];
             vmin = fmin(vmin, r[SG_MIN]); vmax = fmax(vmax, r[SG_MAX]);
+            vmin0 = fmin(vmin0, r[SG_MIN0]); vmax0 = fmax(vmax0, r[SG_MAX0]);
+            vmin1 = fmin(vmin1, r[SG_MIN1]); vmax1 = fmax(vmax1, r[SG_MAX1]);
         }
         const bool constant = !(vmin < vmax);
+        // a HALF of the chain can be constant when the chain is not (a few draws, heavy ties: the one odd draw is the last
+        // of an odd-length chain, which the split drops): its squared deviations are exactly zero in the reference
+        // (diagnostics.py:196-201 on equal values), and Q - S m is that only up to rounding
+        const bool const0 = constant || !(vmin0 < vmax0), const1 = constant || !(vmin1 < vmax1);
         const double m = (n > 0) ? S / (double)n : 0.0;
         const u32* zc = z + off[c];
         double th, tt;
@@ -340,8 +349,8 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
             cq[c] = constant ? 0.0 : Q - S * m;
             const double m0 = (nh > 0) ? S0 / (double)nh : 0.0, m1 = (nh > 0) ? S1 / (double)nh : 0.0;
             hm[2 * c] = m0; hm[2 * c + 1] = m1;
-            hq[2 * c] = constant ? 0.0 : fmax(Q0 - S0 * m0, 0.0);
-            hq[2 * c + 1] = constant ? 0.0 : fmax(Q1 - S1 * m1, 0.0);
+            hq[2 * c] = const0 ? 0.0 : fmax(Q0 - S0 * m0, 0.0);
+            hq[2 * c + 1] = const1 ? 0.0 : fmax(Q1 - S1 * m1, 0.0);
             double* cs = chstate + (pk * C + c) * kChState;
             cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = h32; cs[4] = t32;
         }

@@ -195,6 +195,29 @@ def test_heavy_ties_and_constant(ctx, oracle):
     check_summary(ctx.summarize(x, "pcn"), oracle.summarize(x, "pcn"), what="ties")
 
 
+def test_constant_halves_of_a_chain_that_is_not_constant(ctx, oracle):
+    """Found by tests/manual/fuzz_long.py (seed 13, case 390): every draw equal but the LAST one of an odd-length chain,
+    which `_split_chains` drops (diagnostics.py:76-85) -- all half-chains are constant although one chain is not.  The
+    reference's within variance is then exactly 0 (`_variance` on equal values) and `_rhat` returns inf or 1.0 by whether
+    the mean of the equal half means rounds (diagnostics.py:148-150); Q - S m is zero only up to rounding, so the
+    kernels detect constant halves on the rank codes (k_acov_seg: SG_MIN0 .. SG_MAX1)."""
+    x = np.full((3, 6, 5), -171.0)
+    x[0, 2, 4] = -170.0                     # the dropped draw
+    x[1, 0, 4] = -170.0; x[1, 5, 4] = -172.0
+    x[2, 3, 1] = -170.0                     # a draw the split keeps: an ordinary parameter
+    y = np.full((2, 4, 9), 2.5)
+    y[0, 1, 8] = 7.0
+    y[1, 1, 3] = 7.0
+    for arr in (x, y):
+        exp = oracle.summarize(arr, "pcn", min_chains=2)
+        got = ctx.summarize(arr, "pcn", min_chains=2)
+        for k in ("rhat", "rhat_bulk", "rhat_tail", "ess_bulk", "ess_tail"):
+            for a, b in zip(got[k], exp[k]):
+                assert close(a, b, TIGHT), (k, got[k], exp[k])
+        assert np.array_equal(got["lag_bulk"], exp["lag_bulk"]) and np.array_equal(got["lag_tail"], exp["lag_tail"])
+    assert np.isinf(oracle.summarize(x, "pcn", min_chains=2)["rhat"][0])
+
+
 def test_basic_stats_and_compare(ctx, oracle):
     g = load_json("compare_cases.json")
     for rec in g["basic"]:
