@@ -38,6 +38,24 @@ __global__ __launch_bounds__(256) void k_rate(unsigned* out, int iters)
                          "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                          "v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if (KIND == 6) {   // VALU compare into VCC + selects on VCC (VOP2): 1 cmp + 3 cndmask, twice
+            asm volatile("v_cmp_lt_u32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n"
+                         "v_cmp_lt_u32_e32 vcc, %1, %0\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+        } else if (KIND == 7) {   // the same with the compare into an SGPR pair and VOP3 selects
+            unsigned long long s0, s1;
+            asm volatile("v_cmp_lt_u32_e64 %8, %0, %1\n v_cndmask_b32_e64 %2, %2, %10, %8\n v_cndmask_b32_e64 %3, %3, %10, %8\n v_cndmask_b32_e64 %4, %4, %10, %8\n"
+                         "v_cmp_lt_u32_e64 %9, %1, %0\n v_cndmask_b32_e64 %5, %5, %10, %9\n v_cndmask_b32_e64 %6, %6, %10, %9\n v_cndmask_b32_e64 %7, %7, %10, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(s0), "=&s"(s1) : "v"(b));
+        } else if (KIND == 8) {   // fp64 compare into VCC + 6 selects on VCC: one compare-exchange of (f64 key, u32 payload) pairs
+            asm volatile("v_cmp_lt_f64_e32 vcc, %9, %10\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n"
+                         "v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_mov_b32_e32 %6, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(d0), "v"(d1) : "vcc");
+        } else if (KIND == 9) {   // the same compare-exchange with the mask in an SGPR pair (what the compiler emits)
+            unsigned long long s0;
+            asm volatile("v_cmp_lt_f64_e64 %8, %10, %11\n v_cndmask_b32_e64 %0, %0, %9, %8\n v_cndmask_b32_e64 %1, %1, %9, %8\n v_cndmask_b32_e64 %2, %2, %9, %8\n"
+                         "v_cndmask_b32_e64 %3, %3, %9, %8\n v_cndmask_b32_e64 %4, %4, %9, %8\n v_cndmask_b32_e64 %5, %5, %9, %8\n v_mov_b32_e32 %6, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(s0) : "v"(b), "v"(d0), "v"(d1));
         } else {                  // v_fma_f32 for reference
             float f0 = __uint_as_float(a0), f1 = __uint_as_float(a1), f2 = __uint_as_float(a2), f3 = __uint_as_float(a3);
             float f4 = __uint_as_float(a4), f5 = __uint_as_float(a5), f6 = __uint_as_float(a6), f7 = __uint_as_float(a7), g = 1.0001f;
@@ -73,5 +91,7 @@ int main()
     unsigned* out; CK(hipMalloc(&out, 256 * 8 * 256 * 4));
     run<5>("v_fma_f32", out); run<2>("v_add_u32_e32", out); run<0>("v_cndmask_b32_e32(vcc)", out); run<1>("v_cndmask_b32_e64(sgpr)", out);
     run<3>("v_cmp_lt_f64_e64", out); run<4>("v_mov_b32_dpp", out);
+    run<6>("cmp_u32->vcc + 3 sel e32", out); run<7>("cmp_u32->sgpr + 3 sel e64", out);
+    run<8>("CE f64: vcc + 6 sel e32", out); run<9>("CE f64: sgpr + 6 sel e64", out);
     return 0;
 }
