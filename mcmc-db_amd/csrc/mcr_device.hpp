@@ -99,6 +99,18 @@ __device__ __forceinline__ int row_lane(int v, int j)
 template <int CTRL, int ROW_MASK, int OLD>
 __device__ __forceinline__ int dpp_i32_or(int v) { return __builtin_amdgcn_update_dpp(OLD, v, CTRL, ROW_MASK, 0xf, false); }
 
+// exclusive prefix sums of one u32 per lane (+ the wave total): the six-step DPP scan on integers
+__device__ __forceinline__ u32 wave_excl_scan_u32(u32 v, u32& total)
+{
+    int incl = (int)v;
+    incl += dpp_i32_or<0x111, 0xf, 0>(incl); incl += dpp_i32_or<0x112, 0xf, 0>(incl);
+    incl += dpp_i32_or<0x114, 0xf, 0>(incl); incl += dpp_i32_or<0x118, 0xf, 0>(incl);      // row_shr 1, 2, 4, 8
+    incl += dpp_i32_or<0x142, 0xa, 0>(incl);                                               // row_bcast:15 -> rows 1, 3
+    incl += dpp_i32_or<0x143, 0xc, 0>(incl);                                               // row_bcast:31 -> rows 2, 3
+    total = (u32)__builtin_amdgcn_readlane(incl, 63);
+    return (u32)incl - v;
+}
+
 // inclusive prefix maximum (values >= -1); `excl` <- the prefix maximum of the lanes before this one (-1 in lane 0)
 __device__ __forceinline__ int wave_prefix_max(int v, int& excl)
 {
