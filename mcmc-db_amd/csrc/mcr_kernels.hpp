@@ -645,8 +645,13 @@ __device__ __forceinline__ i64 wave_order_stats(const KT* __restrict__ k, i64 M,
         const double a = sorted_key(k, lo), b = sorted_key(k, hi), d = b - a, g = q.g[j];
         res[(R_Q0 + j) * P + p] = (g >= 0.5) ? b - d * (1.0 - g) : a + d * g;
     }
-    const double med = (M & 1) ? sorted_key(k, M / 2) : (sorted_key(k, M / 2 - 1) + sorted_key(k, M / 2)) / 2.0;
+    // the two middle draws give the median and, unless draws tie AT the median, the split point too: with below < med
+    // every draw up to index M/2 - 1 is below the median and the one at M/2 is not, so s = M/2 and the search (three
+    // dependent rounds of loads in front of every fold workgroup's merge) is skipped
+    const double below = (M >= 2) ? sorted_key(k, M / 2 - 1) : -INFINITY, at = sorted_key(k, M / 2);
+    const double med = (M & 1) ? at : (below + at) / 2.0;
     if (write && lane == 0) res[R_MEDIAN * P + p] = med;
+    if (below < med) { med_out = med; return M / 2; }
     i64 lo = 0, hi = M;  // first index with k[i] >= med lies in [lo, hi]
     while (lo < hi) {
         const i64 step = (hi - lo + 63) / 64;
