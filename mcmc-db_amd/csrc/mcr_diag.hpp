@@ -172,7 +172,8 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     __shared__ __attribute__((aligned(16))) double sx[LX];
     __shared__ __attribute__((aligned(16))) double scr2[FIRST ? 8 : NW * 4 * 64];
     __shared__ double tot[64];
-    __shared__ double wred[NW * 4 * 12];
+    __shared__ double wred[NW * 4 * 8];     // (the half windows' min / max go through `tot`, free until the lag products are reduced:
+                                            //  512 more bytes here cost the seventh resident workgroup per CU)
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;
@@ -232,17 +233,21 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
         S = row_sum(S); S0 = row_sum(S0); Q0 = row_sum(Q0); S1 = row_sum(S1); Q1 = row_sum(Q1);
         cmin = row_min_u32(cmin); cmax = row_max_u32(cmax);
         c0min = row_min_u32(c0min); c0max = row_max_u32(c0max); c1min = row_min_u32(c1min); c1max = row_max_u32(c1max);
+        static_assert(NW * 4 * 4 <= 64, "the four half-window fields of every DPP row fit `tot`");
         if ((tid & 15) == 0) {
-            double* q = wred + (tid >> 4) * 12;
+            double* q = wred + (tid >> 4) * 8;
             q[0] = S; q[1] = S0; q[2] = Q0; q[3] = S1; q[4] = Q1; q[5] = (double)cmin; q[6] = (double)cmax;
-            q[7] = (double)c0min; q[8] = (double)c0max; q[9] = (double)c1min; q[10] = (double)c1max;
+            double* q2 = tot + (tid >> 4) * 4;
+            q2[0] = (double)c0min; q2[1] = (double)c0max; q2[2] = (double)c1min; q2[3] = (double)c1max;
         }
         __syncthreads();
         double* r = rec + ((pk * C + c) * (i64)nseg + seg) * kSegRec;
         if (tid < 11) {
-            double t = wred[tid];
+            const double* src = (tid < 7) ? wred + tid : tot + (tid - 7);
+            const int stride = (tid < 7) ? 8 : 4;
+            double t = src[0];
             for (int w = 1; w < NW * 4; ++w) {
-                const double x = wred[w * 12 + tid];
+                const double x = src[w * stride];
                 t = (tid < 5) ? t + x : (((tid & 1) == 1) ? fmin(t, x) : fmax(t, x));      // 5, 7, 9: minima; 6, 8, 10: maxima
             }
             r[SG_S + tid] = t;        // SG_S, SG_S0, SG_Q0, SG_S1, SG_Q1, SG_MIN, SG_MAX, SG_MIN0 .. SG_MAX1 are consecutive
