@@ -529,7 +529,7 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     for (i64 R = kTile; R < Rstop; R *= 2) {
         LAUNCH(ctx, K_MERGE, (k_merge<MNT, MVT, false, IdxT>), dim3(nblk, py), dim3(MNT), lds_tile + 256,
                (const double*)kin, (const IdxT*)iin, kout, iout, M, R, (double*)nullptr, pc,
-               QArgs{}, (u32*)nullptr);
+               QArgs{}, (u32*)nullptr, (const i64*)nullptr);
         std::swap(kin, kout);
         std::swap(iin, iout);
     }
@@ -557,12 +557,17 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
     return MCR_OK;
 }
 
+// Order statistics by the fold kernel's own workgroups (a launch less) while a parameter has few of them; a pooled
+// array beyond 16-bit positions has a hundred fold workgroups per parameter, and one k_order_stats launch serves them.
+inline bool order_stats_in_fold(const PipeIn& a) { return a.do_diag && a.M <= kIdx16Max; }
+inline const i64* fold_split(const PipeIn& a) { return order_stats_in_fold(a) ? (const i64*)nullptr : (const i64*)a.split; }
+
 template <typename IdxT, int NT, int VT>
 int launch_fold_rec(mcr_ctx* ctx, PipeIn& a, double* kin, unsigned fgrid)
 {
     LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT, u64>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile),
            (const u64*)kin, (const IdxT*)nullptr, (double*)nullptr, (IdxT*)nullptr, a.M, (i64)0, a.d_res, a.pc,
-           a.q, a.zt);
+           a.q, a.zt, fold_split(a));
     return MCR_OK;
 }
 
@@ -571,7 +576,7 @@ int launch_fold(mcr_ctx* ctx, PipeIn& a, double* kin, void* iin, double* kout, v
 {
     LAUNCH(ctx, K_FOLD_MERGE, (k_merge<NT, VT, true, IdxT>), dim3(fgrid), dim3(NT), sort_lds_bytes<IdxT>(kTile) + ctx->dbg_lds_pad[2],
            (const double*)kin, (const IdxT*)iin, kout, (IdxT*)iout, a.M, (i64)0, a.d_res, a.pc,
-           a.q, a.zt);
+           a.q, a.zt, fold_split(a));
     return MCR_OK;
 }
 
@@ -679,7 +684,7 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         if (rc) return rc;
     }
     // 3. order statistics: with diagnostics, by the fold kernel itself; a launch of their own for Backend.stats calls
-    if (!a.do_diag) {
+    if (!order_stats_in_fold(a)) {
         if (use_records(a)) {
             LAUNCH(ctx, K_ORDER_STATS, k_order_stats<u64>, dim3((unsigned)((pc + 3) / 4)), dim3(256), 0,
                    (const u64*)kin, M, pc, a.q, a.d_res, a.split);

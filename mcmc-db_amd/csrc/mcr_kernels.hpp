@@ -679,7 +679,7 @@ template <int NT, int VT, bool FOLD, typename IdxT, typename KT = double>
 __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const IdxT* __restrict__ iin,
                                               double* __restrict__ kout, IdxT* __restrict__ iout, i64 M,
                                               i64 R, double* __restrict__ res, i64 P,
-                                              QArgs q, u32* __restrict__ z)
+                                              QArgs q, u32* __restrict__ z, const i64* __restrict__ split_in)
 {
     constexpr int OBS = NT * VT;                            // LDS slots
     // The fold kernel owns 64 outputs fewer than it has slots and keeps its scratch in the 64 key slots that frees:
@@ -718,7 +718,10 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
         // The order statistics of the parameter, by the first wave of EVERY fold workgroup (a launch of their own in round
         // 2): the median and the split point are three to five dependent loads, the parameter's first workgroup also
         // writes the quantiles and the median.
-        if (tid < 64) {
+        // (long arrays -- a hundred fold workgroups per parameter -- get them from a k_order_stats launch instead: split_in)
+        if (split_in != nullptr) {
+            if (tid == 0) { sh[0] = split_in[p]; reinterpret_cast<double*>(sh)[1] = res[R_MEDIAN * P + p]; }
+        } else if (tid < 64) {
             double m_;
             const i64 s_ = wave_order_stats(kp, M, q, blk == 0, res, P, p, m_);
             if (tid == 0) { sh[0] = s_; reinterpret_cast<double*>(sh)[1] = m_; }
