@@ -11,13 +11,14 @@
 //   k_splitters     exact k-way partition by regular sampling: deterministic bucket bound
 //   k_bucket_merge  per bucket: gather <= 16 sorted pieces, merge in LDS, write the pooled ascending
 //                   order, and (fused) tie-averaged ranks -> rank code -> time order                 (a7)
-//   k_order_stats   quantiles, median, fold split point                                        (a2/a3/a8)
+//   (order statistics: quantiles, median, fold split point -- by the first wave of every fold workgroup;
+//    a k_order_stats launch of their own for Backend.stats calls and for pooled arrays beyond 64K)      (a2/a3/a8)
 //   k_merge<true>   |x - med| order by ONE merge of the two monotone halves (no second sort), fused
-//                   with the rank codes of the folded values                                      (a8, a7)
-//   k_acov_seg / k_diag_combine(2) / k_acov_long / k_diag_long_scan (mcr_diag.hpp)
-//                   split R-hat + ESS for bulk and folded z, lags in three tiers; combine2 also packs
-//                   mean / std / rhat = pymax(bulk, tail) into the result table (k_finalize does that
-//                   for calls without diagnostics)                                               (a9-a13)
+//                   with the rank codes of the folded values, their scatter write-combined in LDS   (a8, a7)
+//   k_acov_seg / k_diag_combine(2) / k_tier3 (or k_long_list + k_dev_fill + FFT | k_acov_long + k_diag_long_scan)
+//                   (mcr_diag.hpp, mcr_fft.hpp) split R-hat + ESS for bulk and folded z, lags in three tiers;
+//                   combine2 also packs mean / std / rhat = pymax(bulk, tail) into the result table (k_finalize
+//                   does that for calls without diagnostics)                                       (a9-a13)
 //   (k_rank_z: the standalone rank kernel, used only when M > 512K and no bucket partition applies)
 //
 // (aN) = row of SURVEY.md section 8(a); reference file:line citations are next to each kernel.
