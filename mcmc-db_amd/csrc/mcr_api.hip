@@ -421,7 +421,8 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     }
     LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64u * (unsigned)(a.C < kCombineWaves ? a.C : kCombineWaves)), (size_t)6 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate,
-           a.long_count, a.long_list);      // (long_list doubles as k_tier3's per-pair counters)
+           a.long_count, a.long_list,       // (long_list doubles as k_tier3's per-pair counters)
+           ctx->rho_band, ctx->guard_count);
     // tier 2 for pairs whose first negative rho lies beyond lag 63 (others exit at once)
     if (small) {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
@@ -436,15 +437,16 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
            a.n, nseg, (const double*)a.rec2, (const unsigned*)a.more, a.state,
-           (const double*)a.chstate, a.d_res, a.pc, a.kA, a.kB,   // kA / kB: the sort's key buffers, free by now
-           (const double*)a.part, (int)a.ntiles, fused_tier3 ? 0 : 1);
+           a.chstate, a.d_res, a.pc, a.kA, a.kB,   // kA / kB: the sort's key buffers, free by now
+           (const double*)a.part, (int)a.ntiles, fused_tier3 ? 0 : 1, ctx->rho_band, ctx->guard_count);
     if (a.n <= kLag2) return MCR_OK;       // chains short enough to be decided by lag 255 never reach tier 3
     if (fused_tier3) {
         // the common case in one launch: list, products of the single round [256, n) and scan (k_tier3)
         const unsigned groups = (unsigned)((a.n - kLag2 + kLongGroup - 1) / kLongGroup);
         const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
         LAUNCH(ctx, K_ACOV_LONG, k_tier3, dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB, a.M, a.d_off,
-               a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, a.long_list);
+               a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, a.long_list,
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.chstate);
         return MCR_OK;
     }
     LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
@@ -492,8 +494,8 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
                (const double*)a.state, a.acov, slot_from);
         LAUNCH(ctx, K_DIAG_LONG, k_diag_long_scan, dim3(scan_slots), dim3(256), 0, a.C, a.n, L0, L1, (const unsigned*)a.long_count,
-               (const unsigned*)a.long_list, a.state, a.acov, a.d_res, a.pc, (const double*)a.kA, (const double*)a.kB, a.M,
-               a.d_off, ctx->rho_band, ctx->guard_count);
+               (const unsigned*)a.long_list, a.state, a.acov, a.d_res, a.pc, (const u32*)a.zb, (const u32*)a.zt,
+               (const double*)a.ztab, a.chstate, a.M, a.d_off, ctx->rho_band, ctx->guard_count);
         L0 = L1;
     }
     return MCR_OK;

@@ -289,9 +289,152 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
 }
 
 // Per-chain state kept between the combine kernels.
-constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), -
+constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), the chain's LEFT-TO-RIGHT mean (NaN until a band lag needs it)
 // Per-pair scan state: rho_sum, terms, var_hat, decided (tier 3)
 constexpr int kPairState = 4;
+
+// ---- GUARD BAND: no `rho < 0` decision on a value within round-off of zero ----
+// The reference stops at the first `rho < 0` (diagnostics.py:171-177) and the number of accumulated terms is an integer
+// output.  Every tier forms its autocovariances in another summation order than _autocorr's left-to-right loop (tier 1 / 2:
+// FMA'd raw products in a register tile, tree sums over lanes and segments, then the cancelling mean correction,
+// ~1e-15 rho_0; tier 3: tree sums ~1e-16 rho_0 or FFTs ~1e-14 rho_0), so a rho that close to zero could take the other sign
+// here than in the reference and move the truncation lag by one.  No decision is therefore taken on such a value: every
+// tier looks for the first lag whose rho is below +band (kRhoBand, MCR_RHO_BAND); if that rho is above -band, the lag is
+// RE-DERIVED THE REFERENCE'S WAY before it is compared with zero (ref_cov_sum below) and the walk resumes behind it when
+// the result is not negative.  Lags outside the band keep the value of their tier.
+constexpr double kRhoBand = 1e-10;
+constexpr int kGuardMax = 64;     // band lags re-derived per pair and kernel (chains up to 32 768 draws; fewer beyond, guard_budget)
+
+// A band lag costs a sequential pass over the chains (one thread per chain adds left to right: ~10 cycles per draw, 45 us
+// for 10 000 draws, 4.5 ms for a million).  The budget bounds what an adversarial tensor (rho exactly zero at many lags of
+// many long chains) can cost a call: 64 lags up to 32 768 draws, proportionally fewer beyond, never fewer than 4; lags
+// beyond the budget are decided on the value their tier has.
+__device__ __forceinline__ int guard_budget(i64 n)
+{
+    const i64 b = (n <= 32768) ? (i64)kGuardMax : ((i64)kGuardMax * 32768) / n;
+    return (int)(b < 4 ? 4 : b);
+}
+
+constexpr int kGuardChains12 = 4, kGuardChunk12 = 128;     // tiers 1 / 2: 8 KB of LDS in the combine kernels
+constexpr int kGuardChains = 8, kGuardChunk = 256;          // tier 3 (inside the union with the products' staging buffers)
+template <int CH, int CK>
+struct GuardLds {
+    double gA[CH][CK], gB[CH][CK];
+    double gcov[CH], gmean[CH];
+    double gsum;
+};
+
+// cov_sum of _autocorr(chains, lag, .) (diagnostics.py:180-193) for one (parameter, kind): per chain
+//     mean = sum(chain[:n]) / n                                   left to right
+//     cov  = sum_i (chain[i] - mean) * (chain[i + lag] - mean)    left to right, the product rounded before it is added (no FMA)
+//     cov /= n - lag ;  cov_sum += cov                             chains in order
+// with chain[i] = ztab[code]: the z the other tiers use.  One thread per chain does the additions, all threads of the
+// workgroup stage the draws (table look-ups, CK per chain at a time) into the LDS for it.  With z equal to the reference's
+// (bit for bit in the central 85 % of the ranks, within 1-2 ulp of the device log in the tails) this IS the reference's
+// cov_sum bit for bit -- its mean included: the tiers' S / n is a tree sum and differs from sum(chain) / n by an ulp
+// (ADVICE r3), so the left-to-right mean is taken here, once per chain, and kept in chstate[.][5].
+// All blockDim.x threads call it with identical arguments; every thread returns the value.
+template <int CH, int CK>
+__device__ __noinline__ double ref_cov_sum(const u32* __restrict__ z, const double* __restrict__ ztab, i64 M,
+                                           const i64* __restrict__ off, int C, i64 n, i64 lag,
+                                           double* __restrict__ chst, GuardLds<CH, CK>& G)
+{
+#pragma clang fp contract(off)      // products and sums round like CPython's
+    const int tid = threadIdx.x, NT = (int)blockDim.x;
+    __syncthreads();
+    if (tid == 0) G.gsum = 0.0;
+    const i64 len = n - lag;
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        const int nc = (C - c0 < CH) ? C - c0 : CH;
+        __syncthreads();
+        if (tid < nc) G.gmean[tid] = chst[(c0 + tid) * kChState + 5];
+        __syncthreads();
+        bool need = false;
+        for (int c = 0; c < nc; ++c) need = need || (G.gmean[c] != G.gmean[c]);
+        if (need) {                                          // the chains' left-to-right means
+            double s = 0.0;
+            for (i64 i0 = 0; i0 < n; i0 += CK) {
+                const int cl = (int)((n - i0 < CK) ? n - i0 : CK);
+                __syncthreads();
+                for (int e = tid; e < nc * CK; e += NT) {
+                    const int c = e / CK, j = e - c * CK;
+                    if (j < cl) G.gA[c][j] = zdec(ztab, z[off[c0 + c] + i0 + j], M);
+                }
+                __syncthreads();
+                if (tid < nc)
+                    for (int j = 0; j < cl; ++j) s += G.gA[tid][j];
+            }
+            if (tid < nc) { const double m = s / (double)n; G.gmean[tid] = m; chst[(c0 + tid) * kChState + 5] = m; }
+            __syncthreads();
+        }
+        double cov = 0.0;
+        for (i64 i0 = 0; i0 < len; i0 += CK) {
+            const int cl = (int)((len - i0 < CK) ? len - i0 : CK);
+            __syncthreads();
+            for (int e = tid; e < nc * CK; e += NT) {
+                const int c = e / CK, j = e - c * CK;
+                if (j < cl) {
+                    const u32* zc = z + off[c0 + c];
+                    const double m = G.gmean[c];
+                    G.gA[c][j] = zdec(ztab, zc[i0 + j], M) - m;
+                    G.gB[c][j] = zdec(ztab, zc[i0 + j + lag], M) - m;
+                }
+            }
+            __syncthreads();
+            if (tid < nc)
+                for (int j = 0; j < cl; ++j) cov += G.gA[tid][j] * G.gB[tid][j];
+        }
+        if (tid < nc) G.gcov[tid] = cov / (double)len;
+        __syncthreads();
+        if (tid == 0)
+            for (int c = 0; c < nc; ++c) G.gsum += G.gcov[c];
+    }
+    __syncthreads();
+    return G.gsum;
+}
+
+// The first truly negative rho among the 64 lags of a block (tiers 1 and 2).  Lane l of WAVE 0 holds rho of lag lb + l
+// (`valid`: the lag exists and enters the walk); every thread of the workgroup calls this, the other waves only help with
+// the re-derivations.  Returns (to every thread) the lane of the first negative rho, 64 if there is none; wave 0's `rho`
+// of a re-derived lag is replaced by the reference's value.
+template <class F>
+__device__ __forceinline__ int first_negative_guarded(double& rho, bool valid, double band, int& budget, F&& rederive,
+                                                      int* s_req, unsigned* __restrict__ guard_count)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int from = 0;
+    unsigned long long exact = 0ull;          // lanes whose rho has been re-derived
+    for (;;) {
+        if (w == 0) {
+            int req = -1, res = 64;
+            for (;;) {
+                unsigned long long low = __ballot(valid && rho < band);
+                low = (from < 64) ? (low & (~0ull << from)) : 0ull;
+                if (!low) break;
+                const int first = __ffsll((long long)low) - 1;
+                const double rf = readlane_f64(rho, first);
+                if (((exact >> first) & 1ull) || rf < -band || budget <= 0) {
+                    if (rf < 0.0) { res = first; break; }
+                    from = first + 1;
+                    continue;
+                }
+                req = first;
+                break;
+            }
+            if (lane == 0) { s_req[0] = req; s_req[1] = res; }
+        }
+        __syncthreads();
+        const int req = s_req[0];
+        if (req < 0) return s_req[1];
+        const double r = rederive(req);          // all threads; barriers inside
+        if (threadIdx.x == 0) atomicAdd(guard_count, 1u);
+        if (w == 0) {
+            if (lane == req) rho = r;
+            exact |= 1ull << req;
+            --budget;
+        }
+    }
+}
 
 // One workgroup per (parameter, kind), one wave per chain (kCombineWaves at most; the chains' record sums, head / tail
 // scans and loads are independent, so this divides the latency chain of the kernel by the number of chains), then wave 0
@@ -303,7 +446,8 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
                                                      int nseg, const double* __restrict__ rec,
                                                      double* __restrict__ res, i64 P, unsigned* __restrict__ more,
                                                      double* __restrict__ state, double* __restrict__ chstate,
-                                                     unsigned* __restrict__ long_count, unsigned* __restrict__ pair_done)
+                                                     unsigned* __restrict__ long_count, unsigned* __restrict__ pair_done,
+                                                     double band, unsigned* __restrict__ guard_count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* cm = reinterpret_cast<double*>(smem);   // C   chain means
@@ -357,15 +501,17 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
             hq[2 * c] = const0 ? 0.0 : fmax(Q0 - S0 * m0, 0.0);
             hq[2 * c + 1] = const1 ? 0.0 : fmax(Q1 - S1 * m1, 0.0);
             double* cs = chstate + (pk * C + c) * kChState;
-            cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = h32; cs[4] = t32;
+            cs[0] = m; cs[1] = S; cs[2] = constant ? 1.0 : 0.0; cs[3] = h32; cs[4] = t32; cs[5] = NAN;
         }
     }
     wcov[w][lane] = covsum;
     __syncthreads();
-    if (w != 0) return;
-    for (int ww = 1; ww < W; ++ww) covsum += wcov[ww][lane];      // fixed order
+    if (w == 0)
+        for (int ww = 1; ww < W; ++ww) covsum += wcov[ww][lane];      // fixed order
     __shared__ double bc[2];   // var_hat, mode (0: NaN, 1: var_hat == 0, 2: scan)
-    if (lane == 0) {
+    __shared__ int s_req[2];
+    __shared__ GuardLds<kGuardChains12, kGuardChunk12> G;
+    if (threadIdx.x == 0) {
         // ---- split R-hat (diagnostics.py:136-151); chains shorter than 2 draws are skipped ----
         int ms = 0;
         for (int k = 0; k < C; ++k) ms += (off[k + 1] - off[k] >= 2) ? 2 : 0;
@@ -410,20 +556,21 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
         }
         bc[0] = vh; bc[1] = mode;
     }
-    __builtin_amdgcn_wave_barrier();         // only wave 0 is left; a wave's LDS accesses execute in order
+    __syncthreads();
     const double vh = bc[0];
     const int mode = (int)bc[1];
-    // ---- rho terms of lags 1..kLag1-1, one per lane; the first negative one stops the sum
-    //      (diagnostics.py:171-177).  The prefix is summed with a wave tree instead of left to right.
+    // ---- rho terms of lags 1..kLag1-1, one per lane of wave 0; the first negative one stops the sum
+    //      (diagnostics.py:171-177), a rho within the guard band of zero being re-derived the reference's way first
+    //      (the other waves stay for that).  The prefix is summed with a wave tree instead of left to right.
     double rho = 0.0;
-    bool neg = false;
     const bool valid = mode == 2 && lane >= 1 && lane < n && lane < kLag1;
-    if (valid) {
-        rho = (covsum / (double)(n - lane)) / ((double)C * vh);
-        neg = rho < 0.0;
-    }
-    const unsigned long long negmask = __ballot(neg);
-    const int first = negmask ? (__ffsll((long long)negmask) - 1) : 64;      // lag of the first negative rho
+    const double den = (double)C * vh;
+    if (valid) rho = (covsum / (double)(n - lane)) / den;
+    int budget = guard_budget(n);
+    const int first = first_negative_guarded(rho, valid && w == 0, band, budget,
+        [&](int l) { return ref_cov_sum(z, ztab, M, off, C, n, (i64)l, chstate + pk * C * kChState, G) / den; },
+        s_req, guard_count);                                                  // lag of the first negative rho (64: none)
+    if (w != 0) return;
     const double rho_sum = wave_sum((valid && lane < first) ? rho : 0.0);
     const int nvalid = (int)__popcll(__ballot(valid && lane < first));
     if (lane != 0) return;
@@ -462,10 +609,12 @@ __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const 
                                               const double* __restrict__ rec2,
                                               const unsigned* __restrict__ more,
                                               double* __restrict__ state,
-                                              const double* __restrict__ chstate,
+                                              double* __restrict__ chstate,
                                               double* __restrict__ res, i64 P,
                                               double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                              double* hb, double (*wcov)[64], double* ctl, bool defer_dev)
+                                              double* hb, double (*wcov)[64], double* ctl, bool defer_dev,
+                                              double band, unsigned* __restrict__ guard_count, int* s_req,
+                                              GuardLds<kGuardChains12, kGuardChunk12>& G)
 {
     constexpr int NW2 = 16;
     const i64 p = blockIdx.x;
@@ -480,6 +629,7 @@ __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const 
     i64 terms = (i64)state[pk * kPairState + 1];
     const double vhat = state[pk * kPairState + 2];
     bool stop = false;
+    int budget = guard_budget(n);
 
     // ---- lags kLag1..kLag2-1, block by block ----
     // hb[c] / tb[c]: running sums of the first / last `lb` draws of chain c (head / tail bases)
@@ -511,18 +661,26 @@ __device__ __forceinline__ void combine2_pair(const u32* __restrict__ zb, const 
             wcov[w][lane] = covsum;
         }
         __syncthreads();
-        if (w == 0) {
-            double covsum = wcov[0][lane];
-            const int nw = (C < NW2) ? C : NW2;
-            for (int ww = 1; ww < nw; ++ww) covsum += wcov[ww][lane];     // fixed order
+        {
+            const double den = (double)C * vhat;
             const i64 lag = lb + lane;
-            const bool valid = lag < n;
-            const double rho = valid ? (covsum / (double)(n - lag)) / ((double)C * vhat) : 0.0;
-            const unsigned long long negmask = __ballot(valid && rho < 0.0);
-            const int first = negmask ? (__ffsll((long long)negmask) - 1) : 64;
-            const double add = wave_sum((valid && lane < first) ? rho : 0.0);
-            const int cnt = (int)__popcll(__ballot(valid && lane < first));
-            if (lane == 0) { ctl[0] = (first < 64) ? 1.0 : 0.0; ctl[1] = add; ctl[2] = (double)cnt; }
+            const bool valid = w == 0 && lag < n;
+            double rho = 0.0;
+            if (w == 0) {
+                double covsum = wcov[0][lane];
+                const int nw = (C < NW2) ? C : NW2;
+                for (int ww = 1; ww < nw; ++ww) covsum += wcov[ww][lane];     // fixed order
+                rho = valid ? (covsum / (double)(n - lag)) / den : 0.0;
+            }
+            // first negative rho of the block; a rho within the guard band of zero is re-derived the reference's way first
+            const int first = first_negative_guarded(rho, valid, band, budget,
+                [&](int l) { return ref_cov_sum(z, ztab, M, off, C, n, lb + (i64)l, chstate + pk * C * kChState, G) / den; },
+                s_req, guard_count);
+            if (w == 0) {
+                const double add = wave_sum((valid && lane < first) ? rho : 0.0);
+                const int cnt = (int)__popcll(__ballot(valid && lane < first));
+                if (lane == 0) { ctl[0] = (first < 64) ? 1.0 : 0.0; ctl[1] = add; ctl[2] = (double)cnt; }
+            }
         }
         __syncthreads();
         rho_sum += ctl[1];
@@ -561,20 +719,23 @@ __global__ __launch_bounds__(1024) void k_diag_combine2(const u32* __restrict__ 
                                                        const double* __restrict__ rec2,
                                                        const unsigned* __restrict__ more,
                                                        double* __restrict__ state,
-                                                       const double* __restrict__ chstate,
+                                                       double* __restrict__ chstate,
                                                        double* __restrict__ res, i64 P,
                                                        double* __restrict__ dev_b, double* __restrict__ dev_t,
-                                                       const double* __restrict__ part, int ntiles, int defer_dev)
+                                                       const double* __restrict__ part, int ntiles, int defer_dev,
+                                                       double band, unsigned* __restrict__ guard_count)
 {
     __shared__ double ctl[3];
     __shared__ double wcov[16][64];
+    __shared__ int s_req[2];
+    __shared__ GuardLds<kGuardChains12, kGuardChunk12> G;
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x;
     // pooled mean / std from the tile partials and rhat = pymax(bulk, tail) (k_diag_combine wrote both): the work of
     // k_finalize, done here by the first thread of the parameter's first workgroup
     if (blockIdx.y == 0 && tid == 0) finalize_param(part, ntiles, M, P, C, res, blockIdx.x);
     combine2_pair(zb, zt, ztab, M, off, C, n, nseg, rec2, more, state, chstate, res, P, dev_b, dev_t,
-                  reinterpret_cast<double*>(smem2), wcov, ctl, defer_dev != 0);
+                  reinterpret_cast<double*>(smem2), wcov, ctl, defer_dev != 0, band, guard_count, s_req, G);
 }
 
 // Deviations z - mean of the listed pairs, in time order, for tier 3: grid (chunks of 4096 pooled draws, slots), block 256.
@@ -690,38 +851,26 @@ __global__ __launch_bounds__(NT) void k_acov_long(const double* __restrict__ dev
 }
 
 // Tier 3 scan of one round's lags [L0, min(L1, n)) for the listed pairs: first negative rho, ordered prefix sum.
-// grid (kLongSlots), block 256.
-//
-// GUARD BAND.  The reference stops at the first `rho < 0` (diagnostics.py:171-177).  The tier-3
-// autocovariances carry round-off -- ~1e-14 rho_0 from the FFTs of mcr_fft.hpp, ~1e-16 rho_0 from the tree sums of
-// k_acov_long -- so a rho that close to zero could take the other sign here than in the reference's own sum, and move the
-// integer truncation lag.  No decision is therefore taken on such a value: the scan looks for the first lag whose rho is
-// below +kRhoBand; if that rho is above -kRhoBand it is RE-DERIVED THE REFERENCE'S WAY before it is compared with zero --
-// per chain one thread adds the rounded products (z_i - m)(z_{i+lag} - m) left to right, no FMA, divides by (n - lag),
-// the chains are added in order (diagnostics.py:185-192) -- and the scan resumes behind it when it is not negative.  With
-// deviations that equal the reference's (they do whenever z does, i.e. outside the 1-2 ulp of the device log in the far
-// tails) this is the reference's own rho bit for bit, whichever engine produced the lag's first estimate; every lag
-// outside the band keeps its FFT / tree value.  A band lag costs one sequential pass over the chain (~0.15 ms for 32 768
-// draws); at most kGuardMax of them are re-derived per pair and round, further ones are decided on the value they have.
-constexpr double kRhoBand = 1e-10;
-constexpr int kGuardMax = 64;
-constexpr int kGuardChunk = 256, kGuardChains = 8;
-
+// grid (kLongSlots), block 256.  Guard band as in tiers 1 and 2 (see ref_cov_sum): the scan looks for the first lag whose
+// rho is below +band; inside (-band, +band) the lag is re-derived with _autocorr's own sums before it is compared with
+// zero, and the scan resumes behind it when it is not negative.  A band lag costs one sequential pass over the chains
+// (~0.15 ms for 32 768 draws, 4.5 ms for a million); at most guard_budget(n) of them are re-derived per pair and round,
+// further ones are decided on the value they have.
 struct ScanLds {
     double red[4];
     long long sfirst;
-    double gA[kGuardChains][kGuardChunk], gB[kGuardChains][kGuardChunk];
-    double gcov[kGuardChains];
-    double gsum;
+    GuardLds<kGuardChains, kGuardChunk> G;
 };
 
-// The scan of one listed pair over the lags [L0, lend).  All 256 threads call it.
+// The scan of one listed pair over the lags [L0, lend).  All 256 threads call it.  z: the pair's rank codes (time order);
+// chst: its chains' state records.  mark: set state[pk][3] when the pair is decided (the listed route's rounds test it;
+// k_tier3 must NOT -- its workgroups build their lists from that word while other workgroups scan: ADVICE r3).
 __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64 lend, double* __restrict__ state,
                                                double* __restrict__ acov, double* __restrict__ res, i64 P,
-                                               const double* __restrict__ dev, const i64* __restrict__ off, double band,
-                                               unsigned* __restrict__ guard_count, ScanLds& S)
+                                               const u32* __restrict__ z, const double* __restrict__ ztab, i64 M,
+                                               double* __restrict__ chst, const i64* __restrict__ off, double band,
+                                               unsigned* __restrict__ guard_count, bool mark, ScanLds& S)
 {
-#pragma clang fp contract(off)      // the re-derived products and sums round like CPython's
     const int tid = threadIdx.x;
     double* stp = state + pk * kPairState;
     const double vhat = stp[2];
@@ -729,7 +878,7 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
     const double den = (double)C * vhat;
     const double thr = band * den;
     i64 from = L0, first = lend;
-    int budget = kGuardMax;
+    int budget = guard_budget(n);
     for (;;) {
         if (tid == 0) S.sfirst = (long long)lend;
         __syncthreads();
@@ -750,32 +899,7 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
         }
         --budget;
         // ---- inside the band: the reference's own sum for this lag ----
-        if (tid == 0) S.gsum = 0.0;
-        for (int c0 = 0; c0 < C; c0 += kGuardChains) {
-            const int nc = (C - c0 < kGuardChains) ? C - c0 : kGuardChains;
-            double cov = 0.0;
-            const i64 len = n - first;
-            for (i64 i0 = 0; i0 < len; i0 += kGuardChunk) {
-                const int cl = (int)((len - i0 < kGuardChunk) ? len - i0 : kGuardChunk);
-                __syncthreads();
-                for (int e = tid; e < nc * kGuardChunk; e += 256) {
-                    const int c = e / kGuardChunk, j = e - c * kGuardChunk;
-                    if (j < cl) {
-                        const double* dc = dev + off[c0 + c];
-                        S.gA[c][j] = dc[i0 + j]; S.gB[c][j] = dc[i0 + j + first];
-                    }
-                }
-                __syncthreads();
-                if (tid < nc)
-                    for (int j = 0; j < cl; ++j) cov += S.gA[tid][j] * S.gB[tid][j];      // left to right, product rounded first
-            }
-            if (tid < nc) S.gcov[tid] = cov / (double)len;
-            __syncthreads();
-            if (tid == 0)
-                for (int c = 0; c < nc; ++c) S.gsum += S.gcov[c];                          // chains in order
-            __syncthreads();
-        }
-        const double cov_sum = S.gsum;
+        const double cov_sum = ref_cov_sum(z, ztab, M, off, C, n, first, chst, S.G);
         const double rho_x = cov_sum / den;
         if (tid == 0) {
             a[first] = cov_sum * (double)(n - first);      // what the prefix sum below adds for this lag (sign kept)
@@ -797,7 +921,7 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
             const int kind = (int)(pk & 1);
             res[(kind ? R_ESS_TAIL : R_ESS_BULK) * P + p] = (double)((i64)C * n) / (1.0 + 2.0 * rho_sum);
             res[(kind ? R_LAG_TAIL : R_LAG_BULK) * P + p] = terms;
-            stp[3] = 1.0;
+            if (mark) stp[3] = 1.0;
         } else {
             stp[0] = rho_sum; stp[1] = terms;
         }
@@ -810,7 +934,8 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
                                                         const unsigned* __restrict__ long_list,
                                                         double* __restrict__ state, double* __restrict__ acov,
                                                         double* __restrict__ res, i64 P,
-                                                        const double* __restrict__ dev_b, const double* __restrict__ dev_t,
+                                                        const u32* __restrict__ zb, const u32* __restrict__ zt,
+                                                        const double* __restrict__ ztab, double* __restrict__ chstate,
                                                         i64 M, const i64* __restrict__ off, double band,
                                                         unsigned* __restrict__ guard_count)
 {
@@ -820,8 +945,8 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
     for (unsigned slot = blockIdx.x; slot < count; slot += gridDim.x) {
         const i64 pk = long_list[slot];
         if (state[pk * kPairState + 3] != 0.0) continue;
-        long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M, off, band,
-                       guard_count, S);
+        long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
+                       chstate + pk * C * kChState, off, band, guard_count, true, S);
     }
 }
 
@@ -842,7 +967,9 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
                                                const i64* __restrict__ off, int C, i64 n, const unsigned* __restrict__ more,
                                                double* __restrict__ state, double* __restrict__ acov, double* __restrict__ res,
                                                i64 P, double band, unsigned* __restrict__ guard_count,
-                                               unsigned* __restrict__ pair_done)
+                                               unsigned* __restrict__ pair_done, const u32* __restrict__ zb,
+                                               const u32* __restrict__ zt, const double* __restrict__ ztab,
+                                               double* __restrict__ chstate)
 {
     __shared__ __attribute__((aligned(16))) Tier3Lds U;
     __shared__ unsigned short slist[kTier3MaxPairs];
@@ -877,7 +1004,10 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
             if (s_last) __threadfence();                  // acquire: the other groups' lags
         }
         __syncthreads();
-        if (s_last) long_scan_pair(pk, C, n, (i64)kLag2, lend, state, acov, res, P, dev, off, band, guard_count, U.S);
+        // (mark = false: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list whenever it
+        //  starts -- a late workgroup used to see the pairs an early scan had already marked decided as unlisted: ADVICE r3)
+        if (s_last) long_scan_pair(pk, C, n, (i64)kLag2, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
+                                   chstate + pk * C * kChState, off, band, guard_count, false, U.S);
         __syncthreads();
     }
 }

@@ -652,7 +652,8 @@ __device__ __forceinline__ i64 wave_order_stats(const KT* __restrict__ k, i64 M,
     const double below = (M >= 2) ? sorted_key(k, M / 2 - 1) : -INFINITY, at = sorted_key(k, M / 2);
     const double med = (M & 1) ? at : (below + at) / 2.0;
     if (write && lane == 0) res[R_MEDIAN * P + p] = med;
-    if (below < med) { med_out = med; return M / 2; }
+    // (!(at < med): draws near 1e308 can overflow below + at to +inf, and then #(x < med) is M, not M / 2: ADVICE r3)
+    if (below < med && !(at < med)) { med_out = med; return M / 2; }
     i64 lo = 0, hi = M;  // first index with k[i] >= med lies in [lo, hi]
     while (lo < hi) {
         const i64 step = (hi - lo + 63) / 64;

@@ -148,9 +148,12 @@ def load_library():
             # Multi-process RCCL (N > 1 ranks, one per GPU) exchanges device buffers between processes over IPC handles.  The
             # host driver of this platform supports only the dmabuf form; with the HSA runtime's legacy IPC mode (its
             # default) `hipIpcGetMemHandle` fails with "invalid argument" inside ncclCommInitRank.  The runtime reads the
-            # variable when it initialises, i.e. at the first HIP call, so it is set here, before the library is mapped;
-            # a value the launcher exported wins.  It changes nothing for a single process.
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # variable when it initialises, i.e. at the first HIP call, so it is set here, before the library is mapped --
+            # it must precede the first HIP call of the process, whoever makes it; a value the launcher exported wins.
+            # Only for multi-rank launches: a single process has no IPC to do, and the variable is process-global (it would
+            # change the runtime's behaviour for any other HIP library the host application uses: ADVICE r3).
+            if int(os.environ.get("WORLD_SIZE", "1") or "1") > 1:
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             try:
                 L = C.CDLL(str(path))
             except OSError as exc:

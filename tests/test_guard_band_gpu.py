@@ -1,11 +1,13 @@
-"""Guard band of the tier-3 ESS scan + the order of the tier-3 list.
+"""Guard band of the ESS walk in all three tiers + the order of the tier-3 list.
 
 Spec: src/mcmc_ref/diagnostics.py:154-193 -- `_ess` walks the lags and stops at the first `rho < 0`.  For chains of more
 than 16 384 draws the long lags come from FFTs (csrc/mcr_fft.hpp), whose rho carries ~1e-14 of round-off; the scan
 (k_diag_long_scan, csrc/mcr_diag.hpp) therefore decides no lag whose rho lies within 1e-10 of zero on that value: it
 re-derives the lag with _autocorr's own left-to-right sums first.  tests/golden/band_cases.json holds square-wave
 chains whose rho is exactly zero in exact arithmetic at the deciding lag, with what the IMPORTED REFERENCE returned
-(both outcomes occur: its rounding makes that rho +tiny in some cases, -tiny in others)."""
+(both outcomes occur: its rounding makes that rho +tiny in some cases, -tiny in others).  `low_cases` (round 4) are the
+same construction with the zero lag at 4 ... 250: lags the segment records of k_acov_seg and the mean correction of
+k_diag_combine / k_diag_combine2 produce (tiers 1 and 2), which take the same re-derivation (ref_cov_sum)."""
 from __future__ import annotations
 
 import json
@@ -31,8 +33,92 @@ def square_wave(n: int, T: int, shift: int) -> np.ndarray:      # as in tests/go
     return np.where(i < T // 2, 1.0, -1.0)
 
 
-def _cases():
-    return json.loads((GOLD / "band_cases.json").read_text())["cases"]
+def _cases(key="cases"):
+    return json.loads((GOLD / "band_cases.json").read_text())[key]
+
+
+def test_tiers_one_and_two_decide_a_zero_rho_as_the_reference_does(ctx, oracle):
+    """74 square-wave chain sets (C in {2, 4}, n in {1000 ... 10 000}) whose rho is exactly zero in exact arithmetic at a
+    lag between 4 and 250, run through the imported reference (53 keep the zero lag, 21 stop one short of it): the GPU's
+    integer term count equals the reference's on every one, ESS to 1e-12, and each case went through the re-derivation."""
+    cases = _cases("low_cases")
+    assert len(cases) >= 60
+    lags = sorted(c["zero_lag"] for c in cases)
+    assert lags[0] < 8 and any(64 <= l < 256 for l in lags) and lags[-1] < 256          # both tiers
+    outcomes = set()
+    for c in cases:
+        x = np.stack([square_wave(c["n"], c["T"], s) for s in c["shifts"]])[None]
+        exp = oracle.summarize(x, "pcn", min_chains=2)
+        assert int(exp["lag_bulk"][0]) == c["ref_terms"] and float(exp["ess_bulk"][0]) == c["ref_ess_bulk"]
+        outcomes.add(c["ref_terms"] - c["zero_lag"])
+        before = ctx.rho_guard_count()
+        got = ctx.summarize(x, "pcn", min_chains=2)
+        assert int(got["lag_bulk"][0]) == c["ref_terms"], (c, int(got["lag_bulk"][0]))
+        assert abs(got["ess_bulk"][0] - c["ref_ess_bulk"]) <= 1e-12 * c["ref_ess_bulk"], c
+        assert got["ess_tail"][0] == c["C"] * c["n"] and int(got["lag_tail"][0]) == 0        # |x - med| is constant
+        assert ctx.rho_guard_count() > before, c
+    assert outcomes == {0, -1}
+
+
+def test_tiers_one_and_two_without_the_band(ctx, monkeypatch):
+    """MCR_RHO_BAND=0: the segment-record rho decides on its own rounding.  Reported, not asserted (beyond +-1)."""
+    from mcmc_ref_hip import _ffi
+    monkeypatch.setenv("MCR_RHO_BAND", "0")
+    raw = _ffi.Context(0)
+    monkeypatch.delenv("MCR_RHO_BAND")
+    try:
+        cases = _cases("low_cases")
+        off = 0
+        for c in cases:
+            x = np.stack([square_wave(c["n"], c["T"], s) for s in c["shifts"]])[None]
+            got = raw.summarize(x, "pcn", min_chains=2)
+            assert abs(int(got["lag_bulk"][0]) - c["ref_terms"]) <= 1
+            off += int(got["lag_bulk"][0]) != c["ref_terms"]
+        assert raw.rho_guard_count() == 0
+        print(f"\nwithout the guard band {off} of {len(cases)} tier-1/2 truncation lags differ from the reference's")
+    finally:
+        raw.close()
+
+
+def test_a_batch_of_band_cases_in_one_call(ctx):
+    """Many parameters of one call inside the band at once (every workgroup of k_diag_combine / combine2 re-deriving):
+    the cases that share (C, n) stacked into one tensor give the same answers as one by one."""
+    cases = [c for c in _cases("low_cases") if c["C"] == 4 and c["n"] == 4000]
+    assert len(cases) >= 8
+    x = np.stack([np.stack([square_wave(c["n"], c["T"], s) for s in c["shifts"]]) for c in cases])
+    got = ctx.summarize(x, "pcn")
+    assert [int(v) for v in got["lag_bulk"]] == [c["ref_terms"] for c in cases]
+    assert np.allclose(got["ess_bulk"], [c["ref_ess_bulk"] for c in cases], rtol=1e-12, atol=0)
+
+
+def test_tier3_lists_do_not_depend_on_when_a_workgroup_starts(ctx, oracle):
+    """k_tier3's workgroups each compact the list of undecided pairs, and a scan that finished early used to
+    take its pair off the list a late workgroup saw.  Several calls in flight on the lanes (staggered workgroup starts),
+    each with many listed pairs of very different truncation lags against two slots per launch; every call must equal
+    the oracle."""
+    rng = np.random.default_rng(77)
+    xs = []
+    for k in range(6):
+        x = np.cumsum(rng.normal(size=(10, 4, 3000 + 500 * k)), axis=2) * 0.01
+        x[2 * (k % 3)] = rng.normal(size=x.shape[1:])               # some pairs decided at lag 1
+        x[5, :, : 1500] = rng.normal(size=(4, 1500)) * 3.0            # short memory: a scan that ends early
+        xs.append(x)
+    exps = [oracle.summarize(x, "pcn") for x in xs]
+    assert sum(int((e["lag_bulk"] > 256).sum() + (e["lag_tail"] > 256).sum()) for e in exps) >= 40
+    ts = [ctx.upload(x, "pcn") for x in xs]
+    try:
+        for _ in range(3):
+            bufs = [ctx.enqueue(t) for t in ts]
+            ctx.wait()
+            for b, e in zip(bufs, exps):
+                g = b.result()
+                for k in ("lag_bulk", "lag_tail"):
+                    assert np.array_equal(g[k], e[k]), k
+                for k in ("ess_bulk", "ess_tail", "rhat"):
+                    assert np.allclose(g[k], e[k], rtol=1e-9, atol=0), k
+    finally:
+        for t in ts:
+            t.free()
 
 
 def test_fft_direct_and_reference_agree_where_rho_is_zero(ctx, oracle, monkeypatch):
