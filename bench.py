@@ -14,6 +14,11 @@ No torch anywhere: for N > 1 the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MAS
 the launcher sets and talk through the library's RCCL communicator (mcmc_ref_hip.shard.Communicator:
 barrier, MAX-over-ranks clock, and the one all-gather of the per-parameter summary records).
 
+At N = 1 the default run also carries `configs` (every other single-GPU BASELINE configuration, driver-timed in the same
+process: the 57 committed corpus files end to end, the corpus shapes device-resident, the full pipeline on the 16 GB
+stress tensor), `d_sweep` (P = 10 / 100 / 1000 at 4 x 10000), `sync_call_us` / `host_call_us` (ONE synchronous call, which
+is what reference.compare pays) -- each with its own `validated` flag; --no-extras skips them.
+
 Workloads (--workload):
   c1       BASELINE config 1, the headline: every rank its own 4 x 10000 x 100 f64 model (weak scaling)
   c1split  ONE such model, its P axis cut into contiguous blocks over the ranks (strong scaling)
@@ -54,7 +59,7 @@ ALG_BYTES_PER_PD = {
 
 
 # profile_get() name -> name in profiles/pmc_traffic.json where they differ
-TRAFFIC_NAMES: dict[str, str] = {"k_acov_long": "k_tier3"}      # the HIP-event label of tier 3 covers k_tier3 (chains up to 16 384 draws)
+TRAFFIC_NAMES: dict[str, str] = {}
 
 
 def cpu_model() -> str:
@@ -99,6 +104,8 @@ def parse_args():
     ap.add_argument("--no-moments", action="store_true",
                     help="skip the streaming-moments HBM roofline leg (16 GB f32 tensor generated on the device)")
     ap.add_argument("--no-probe", action="store_true", help="skip the measured-HBM-peak probe")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other single-GPU configurations of the default line (configs / d_sweep / call latencies)")
     return ap.parse_args()
 
 
@@ -137,6 +144,12 @@ class Ranks:
     def max(self, x: float) -> float:
         return float(self.comm.all_reduce([x], "max")[0]) if self.comm is not None else x
 
+    def gather(self, x: float) -> list[float]:
+        """x of every rank, in rank order (the per-rank clocks of the rank-0 line: a slow rank shows in SCALE_rNN.json)."""
+        if self.comm is None:
+            return [float(x)]
+        return [float(v) for v in np.asarray(self.comm.all_gather(np.array([x], dtype=np.float64))).reshape(-1)]
+
     def all_true(self, flag: bool) -> bool:
         return bool(self.comm.all_reduce([1.0 if flag else 0.0], "min")[0] > 0.5) if self.comm is not None else flag
 
@@ -157,10 +170,13 @@ def timed_windows(a, ranks: Ranks, run) -> tuple[float, list[float], object]:
     handle of the last window)."""
     run(a.warmup)
     secs, last = [], None
+    ranks.own_secs = []                                           # this rank's own clock per window (before the MAX)
     while True:
         ranks.barrier()
         t0 = time.perf_counter()
         last = run(a.steps)
+        ranks.ctx.sync()
+        ranks.own_secs.append(time.perf_counter() - t0)
         ranks.barrier()
         secs.append(ranks.max(time.perf_counter() - t0))          # the same value on every rank
         if a.windows > 0:
@@ -237,6 +253,7 @@ def corpus_bench(a, ctx, ranks: Ranks):
     local = np.concatenate(recs) if recs else np.empty((0, shard.RECORD_DOUBLES))
     allrec = shard.gather_records(local, ranks.comm)
     valid = ranks.all_true(valid and allrec.shape[0] == 460)
+    per_rank_ms = [x / a.steps * 1e3 for x in ranks.gather(statistics.median(ranks.own_secs))]
     if rank == 0:
         value = a.steps * total_pd / elapsed
         print(json.dumps({
@@ -248,6 +265,7 @@ def corpus_bench(a, ctx, ranks: Ranks):
                        "sharding": f"whole models, greedy LPT over {world} rank(s), same-shape models batched, "
                                    "one RCCL all-gather of 128-byte records"},
             "validated": valid, "pipeline_alg_GBps": value * 8 / 1e9,
+            "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms],
             "ms_per_step_windows": [s / a.steps * 1e3 for s in windows]}), flush=True)
     return 0 if valid else 1
 
@@ -290,29 +308,17 @@ def split_bench(a, ctx, ranks: Ranks):
         if not a.no_validate:
             from oracle import oracle as orc
             if stress:
-                p = np.arange(p0, p1)
-                sig = 10.0 ** ((p % 7) - 3)
-                M = C * N
-                fine = sig >= 64.0 * np.spacing(np.maximum(p, 1).astype(np.float32)).astype(np.float64)   # sigma well above the f32 grid at p
-                valid = bool(np.all(np.abs(got["mean"] - p)[fine] < 0.02 * sig[fine]) and np.all(np.abs(got["std"] / sig - 1)[fine] < 0.02)
-                             and np.all(got["std"] > 0) and np.all(np.abs(got["mean"] - p) < 0.02 * sig + 1e-3)
-                             and np.all(got["q"][:, 0] <= got["q"][:, 1]) and np.all(got["q"][:, 1] <= got["q"][:, 2])
-                             and np.array_equal(got["q"][:, 1], got["median"])
-                             and np.all((got["ess_bulk"] > 0) & (got["ess_bulk"] <= M)) and np.all((got["ess_tail"] > 0) & (got["ess_tail"] <= M))
-                             and np.all(got["rhat"] >= got["rhat_bulk"]) and np.all(got["rhat"] < 1.01)
-                             and np.all(got["lag_bulk"] >= 0) and np.all(got["lag_tail"] >= 0))
-                sel = np.unique(np.linspace(0, pb - 1, 16).astype(int))
-                sub = np.stack([ctx_row(ctx, t, int(i), M) for i in sel])      # 16 rows of the block, not the block
-                ok, worst = validate({k: (v[sel] if k != "q_lo" else v) for k, v in got.items()},
-                                     orc.summarize(sub.reshape(len(sel), C, N), "pcn"))
+                valid = stress_properties(got, np.arange(p0, p1), C * N)
+                ok, worst, how = stress_oracle_check(ctx, t, got, p0, pb, C, N, synth, orc)
                 valid = valid and ok
-                checked = f"properties over all {pb} parameters of the block + oracle on {len(sel)}"
+                checked = f"properties over all {pb} parameters of the block + {how}"
             else:
                 valid, worst = validate(got, orc.summarize(host, "pcn"))
                 checked = f"oracle on all {pb} parameters of the block"
     allrec = shard.gather_records(recs, ranks.comm)
     valid = ranks.all_true(valid and allrec.shape[0] == P and
                            np.array_equal(allrec[:, shard.RECORD_FIELDS.index("param_idx")], np.arange(P)))
+    per_rank_ms = [x / a.steps * 1e3 for x in ranks.gather(statistics.median(ranks.own_secs))]
     if rank == 0:
         value = a.steps * C * N * P / elapsed
         es = np.dtype(dt).itemsize
@@ -326,9 +332,237 @@ def split_bench(a, ctx, ranks: Ranks):
                        "layout": "pcn", "sharding": "contiguous parameter blocks, no halo, one RCCL all-gather of records"},
             "validated": valid, "max_rel_err": worst, "validation": checked,
             "pipeline_alg_GBps": value * es / 1e9, "pipeline_frac_of_hbm": value * es / 1e9 / HBM_PEAK_GBS / world,
+            "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms],
             "ms_per_step_windows": [s / a.steps * 1e3 for s in windows]}), flush=True)
     t.free()
     return 0 if valid else 1
+
+
+# =====================================================================================================================
+# The other single-GPU BASELINE configurations, inside the default run.  Rank 0, N = 1 only.  Every
+# leg times its own work between device syncs with the host clock, validates the results of the calls it timed, and
+# reports `validated`; none of them touches `value`.
+# =====================================================================================================================
+def _median_ms(fn, reps: int, sync) -> tuple[float, list[float]]:
+    ts = []
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(ts), ts
+
+
+def leg_call_latency(ctx, t, host, got_pipelined: dict) -> dict:
+    """ONE synchronous call -- what reference.compare(model, actual) pays (src/mcmc_ref/reference.py:107-122) -- on the
+    device-resident tensor (`sync_call_us`) and from host memory, upload included (`host_call_us`, PCIe-inclusive)."""
+    keys = ("mean", "std", "q", "rhat", "ess_bulk", "ess_tail", "lag_bulk", "lag_tail")
+    res = {}
+    for _ in range(3):
+        ctx.summarize(t)
+    dev_ms, dev_all = _median_ms(lambda: res.__setitem__("d", ctx.summarize(t)), 40, ctx.sync)
+    for _ in range(2):
+        ctx.summarize(host, "pcn")
+    host_ms, host_all = _median_ms(lambda: res.__setitem__("h", ctx.summarize(host, "pcn")), 15, ctx.sync)
+    same = all(np.array_equal(res["d"][k], got_pipelined[k], equal_nan=True) and
+               np.array_equal(res["h"][k], got_pipelined[k], equal_nan=True) for k in keys)
+    pd = int(np.prod(host.shape))
+    return {"sync_call_us": round(dev_ms * 1e3, 1), "sync_call_min_us": round(min(dev_all) * 1e3, 1),
+            "host_call_us": round(host_ms * 1e3, 1), "host_call_min_us": round(min(host_all) * 1e3, 1),
+            "sync_call_param_draws_per_s": pd / (dev_ms * 1e-3), "host_call_param_draws_per_s": pd / (host_ms * 1e-3),
+            "host_bytes_uploaded": int(host.nbytes),
+            "what": "median of 40 / 15 synchronous mcr_summarize_dev / mcr_summarize calls on the C1 tensor, one at a time "
+                    "(no pipelining); results bit-equal to the pipelined calls that `value` timed",
+            "validated": bool(same)}
+
+
+def leg_d_sweep(ctx, synth, orc, C: int, N: int, c1_ms: float | None) -> list[dict]:
+    """north_star: throughput on synthetic (4 chains x 10 000 draws x D params).  Pipelined (8 calls in flight) and one
+    synchronous call, D = 10 / 100 / 1000, each validated against the oracle on the calls that were timed."""
+    out = []
+    for P in (10, 100, 1000):
+        host = synth.c1_model(C, N, P, seed=4711)
+        t = ctx.upload(host, "pcn")
+        steps = {10: 400, 100: 200, 1000: 40}[P]
+
+        def run(k):
+            last = None
+            for _ in range(k):
+                if ctx.inflight >= 8:
+                    ctx.wait_one()
+                last = ctx.enqueue(t)
+            ctx.wait()
+            return last
+        run(max(steps // 10, 4))
+        ws = []
+        for _ in range(5):
+            ctx.sync(); t0 = time.perf_counter(); last = run(steps); ctx.sync()
+            ws.append((time.perf_counter() - t0) / steps * 1e3)
+        ms = statistics.median(ws)
+        sync_ms, _ = _median_ms(lambda: ctx.summarize(t), 15, ctx.sync)
+        ok, worst = validate(last.result(), orc.summarize_mt(host, "pcn"))
+        t.free()
+        out.append({"params": P, "shape": f"{C}x{N}x{P} f64", "ms_per_call_pipelined": round(ms, 5),
+                    "param_draws_per_s": C * N * P / (ms * 1e-3), "sync_call_us": round(sync_ms * 1e3, 1),
+                    "us_per_100_params": round(ms * 1e3 * 100 / P, 2), "validated": ok, "max_rel_err": worst})
+    return out
+
+
+def leg_corpus_device(ctx, _ffi, orc, steps: int = 20) -> dict:
+    """BASELINE config 2, device-resident: the 57 packaged model shapes (synthetic draws), same-shape models batched."""
+    from mcmc_ref_hip import corpus
+    models = corpus.synthetic_corpus(seed=4711)
+    groups = {}
+    for i, (_, arr) in enumerate(models):
+        groups.setdefault((arr.shape[1], arr.shape[2]), []).append(i)
+    tensors = []
+    for members in groups.values():
+        big = np.concatenate([models[i][1] for i in members], axis=0)
+        tensors.append((big, ctx.upload(big, "pcn")))
+    total_pd = int(sum(np.prod(m.shape) for _, m in models))
+
+    def run(k):
+        last = None
+        for _ in range(k):
+            cur = []
+            for _, t in tensors:
+                if ctx.inflight >= _ffi.MCR_MAX_INFLIGHT:
+                    ctx.wait_one()
+                cur.append(ctx.enqueue(t))
+            last = cur
+        ctx.wait()
+        return last
+    run(5)
+    ws = []
+    for _ in range(7):
+        ctx.sync(); t0 = time.perf_counter(); last = run(steps); ctx.sync()
+        ws.append((time.perf_counter() - t0) / steps * 1e3)
+    ms = statistics.median(ws)
+    ok = True
+    for (big, t), b in zip(tensors, last):
+        v, _ = validate(b.result(), orc.summarize_mt(big, "pcn"))
+        ok = ok and v
+        t.free()
+    return {"workload": "57 packaged model shapes, 460 params, 4.6 M param-draws, synthetic draws resident in HBM "
+                        "(BASELINE config 2; = --workload corpus)", "ms_per_corpus_pass": round(ms, 5),
+            "param_draws_per_s": total_pd / (ms * 1e-3), "windows_ms": [round(w, 5) for w in ws], "steps_per_window": steps,
+            "validated": bool(ok), "validation": "oracle on all 460 parameters of the last timed pass"}
+
+
+def leg_corpus_files(ctx) -> dict | None:
+    """BASELINE config 2 END TO END: the 57 committed draws files of the reference's packaged corpus (tests/golden/corpus,
+    data files, 42.7 MB) -> mcr_summarize_files (mmap, footer parse, upload, Snappy + page decode on the GPU, statistics)
+    -> the 1 380 goldens the reference packaged in its meta.json files.  File-bytes-to-statistics, page cache warm."""
+    from mcmc_ref_hip import parquet
+    root = ROOT / "tests" / "golden" / "corpus"
+    paths = sorted((root / "draws").glob("*.draws.parquet"))
+    if len(paths) != 57:
+        return None
+    res = parquet.summarize_files(ctx, paths, min_chains=4)
+    ms, all_ms = _median_ms(lambda: parquet.summarize_files(ctx, paths, min_chains=4), 9, ctx.sync)
+    c_ms, c_all = _median_ms(lambda: parquet._summarize_paths(ctx, [str(p) for p in paths], 4, [0.05, 0.5, 0.95], True), 9, ctx.sync)
+    res = parquet.summarize_files(ctx, paths, min_chains=4)
+    n_vals, worst, total_pd = 0, 0.0, 0
+    for path, got in zip(paths, res):
+        meta = json.loads((root / "meta" / (path.name[: -len(".draws.parquet")] + ".meta.json")).read_text())
+        total_pd += meta["n_chains"] * meta["n_draws_per_chain"] * len(meta["parameters"])
+        for prm, gold in meta["diagnostics"].items():
+            for k in ("rhat", "ess_bulk", "ess_tail"):
+                worst = max(worst, abs(got[prm][k] - gold[k]) / max(abs(gold[k]), 1e-300))
+                n_vals += 1
+    return {"workload": f"the {len(paths)} REAL packaged draws files ({sum(p.stat().st_size for p in paths)} file bytes, SNAPPY) "
+                        "-> native Parquet ingest -> statistics, one mcr_summarize_files call, page cache warm "
+                        "(BASELINE config 2 end to end)",
+            "ms_end_to_end": round(ms, 3), "ms_min": round(min(all_ms), 3), "param_draws": total_pd,
+            "param_draws_per_s": total_pd / (ms * 1e-3),
+            "ms_c_call_only": round(c_ms, 3),
+            "goldens_checked": n_vals, "max_rel_err_vs_packaged_goldens": worst,
+            "validated": bool(n_vals >= 1300 and worst <= 1e-6),
+            "validation": "rhat / ess_bulk / ess_tail of every parameter against the reference's own meta.json goldens (<= 1e-6)"}
+
+
+def stress_properties(got: dict, p: np.ndarray, M: int) -> bool:
+    """Size-independent properties of the stress tensor's statistics (generator: mu_p = p, sigma_p = 10**((p mod 7) - 3), iid)."""
+    sig = 10.0 ** ((p % 7) - 3)
+    fine = sig >= 64.0 * np.spacing(np.maximum(p, 1).astype(np.float32)).astype(np.float64)   # sigma well above the f32 grid at p
+    return bool(np.all(np.abs(got["mean"] - p)[fine] < 0.02 * sig[fine]) and np.all(np.abs(got["std"] / sig - 1)[fine] < 0.02)
+                and np.all(got["std"] > 0) and np.all(np.abs(got["mean"] - p) < 0.02 * sig + 1e-3)
+                and np.all(got["q"][:, 0] <= got["q"][:, 1]) and np.all(got["q"][:, 1] <= got["q"][:, 2])
+                and np.array_equal(got["q"][:, 1], got["median"])
+                and np.all((got["ess_bulk"] > 0) & (got["ess_bulk"] <= M)) and np.all((got["ess_tail"] > 0) & (got["ess_tail"] <= M))
+                and np.all(got["rhat"] >= got["rhat_bulk"]) and np.all(got["rhat"] < 1.01)
+                and np.all(got["lag_bulk"] >= 0) and np.all(got["lag_tail"] >= 0))
+
+
+def stress_oracle_check(ctx, t, got: dict, p0: int, pb: int, C: int, N: int, synth, orc) -> tuple[bool, float, str]:
+    """The oracle on 128 parameters of the block: both sides of every workspace-chunk edge, every scale of the generator,
+    the all-ties parameters at the f32 grid (synth.stress_check_sample), on all host threads."""
+    sel = synth.stress_check_sample(pb, ctx.params_per_chunk(t), 128)
+    sub = np.stack([ctx_row(ctx, t, int(i), C * N) for i in sel])      # rows of the block, not the block
+    ok, worst = validate({k: (v[sel] if k != "q_lo" else v) for k, v in got.items()},
+                         orc.summarize_mt(sub.reshape(len(sel), C, N), "pcn"))
+    return ok, worst, f"oracle on {len(sel)} (chunk edges of {ctx.params_per_chunk(t)}-parameter chunks, all 7 scales, all-ties)"
+
+
+def leg_stress(_ffi, synth, orc, device: int, peak_measured, pipeline: bool = True) -> tuple[dict | None, dict | None]:
+    """BASELINE config 4 on its own single-lane context: 4 x 100000 x 10000 f32 = 16 GB generated on the device; the
+    streaming-moments roofline (one HBM pass) and the FULL pipeline over all 10 000 parameters (chunked through the
+    workspace), validated by properties over every parameter + the oracle on 128."""
+    os.environ["MCR_LANES"] = "1"
+    ctx = _ffi.Context(device)
+    os.environ.pop("MCR_LANES", None)
+    mc, mn, mp = 4, 100000, 10000
+    try:
+        try:
+            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
+        except _ffi.McrError:                      # a smaller device: quarter-size tensor
+            mp = 2500
+            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
+        ctx.fill_synthetic(big, 4711)
+        ctx.moments(big)
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(5):
+            mm, ms = ctx.moments(big)
+        pm = ctx.profile_get()["k_moments"]
+        ctx.profile(False)
+        kms = pm["total_ms"] / pm["launches"]
+        sig = 10.0 ** ((np.arange(mp) % 7) - 3)
+        ok_m = bool(np.max(np.abs(mm - np.arange(mp)) / sig) < 0.05 and np.max(np.abs(ms / sig - 1)) < 0.05)
+        gbs = mc * mn * mp * 4 / (kms * 1e-3) / 1e9
+        moments = {"kernel": "k_moments_rows<float>", "workload": f"{mc}x{mn}x{mp} f32 ({mc * mn * mp * 4 / 1e9:.0f} GB) synthetic, on-device",
+                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s",
+                   "frac": gbs / HBM_PEAK_GBS, "frac_of_measured": (gbs / peak_measured) if peak_measured else None,
+                   "avg_launch_us": kms * 1e3, "param_draws_per_s": mc * mn * mp / (kms * 1e-3), "sane": ok_m,
+                   "traffic": None, "traffic_source": None}
+        tr = traffic_table().get("moments-4x100000x2500-f32")
+        if tr is not None and mp == 2500:
+            moments["traffic"], moments["traffic_source"] = tr.get("k_moments"), str(TRAFFIC_FILE.relative_to(ROOT))
+        if not pipeline:
+            big.free()
+            return moments, None
+        # ---- the full pipeline on the same tensor ----
+        ctx.summarize(big)                                     # warm-up: workspace allocation, z table
+        ts = []
+        for _ in range(3):
+            ctx.sync(); t0 = time.perf_counter(); got = ctx.summarize(big); ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        sec = statistics.median(ts)
+        ok = stress_properties(got, np.arange(mp), mc * mn)
+        ok2, worst, how = stress_oracle_check(ctx, big, got, 0, mp, mc, mn, synth, orc)
+        big.free()
+        pd = mc * mn * mp
+        stress = {"workload": f"stress: {mc}x{mn}x{mp} f32 ({pd * 4 / 1e9:.0f} GB) generated on the device, ALL {mp} parameters "
+                              "through the full pipeline, chunked through the workspace (BASELINE config 4)",
+                  "ms_per_step": round(sec * 1e3, 2), "steps_ms": [round(x * 1e3, 2) for x in ts], "param_draws_per_s": pd / sec,
+                  "alg_GBps": pd * 4 / sec / 1e9, "frac": pd * 4 / sec / 1e9 / HBM_PEAK_GBS,
+                  "frac_of_measured": (pd * 4 / sec / 1e9 / peak_measured) if peak_measured else None,
+                  "validated": bool(ok and ok2), "max_rel_err": worst,
+                  "validation": f"properties over all {mp} parameters + {how}"}
+        return moments, stress
+    finally:
+        ctx.close()
 
 
 def ctx_row(ctx, t, i: int, M: int) -> np.ndarray:
@@ -487,37 +721,31 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
     probe = hbm_probe(ctx, a) if rank == 0 else None
     peak_measured = probe.get("read_GBps") if probe and "error" not in probe else None
 
-    moments = None
+    moments, extras = None, {}
+    if rank == 0 and world == 1 and not a.no_extras and a.layout == "pcn" and a.dtype == "f64":
+        from oracle import oracle as orc          # checker of every leg below
+        extras["configs"] = {}
+        lat = leg_call_latency(ctx, t, host, got)
+        extras["sync_call_us"], extras["host_call_us"] = lat["sync_call_us"], lat["host_call_us"]
+        extras["call_latency"] = lat
+        extras["d_sweep"] = leg_d_sweep(ctx, synth, orc, C, N, elapsed / a.steps * 1e3)
+        extras["configs"]["corpus_device"] = leg_corpus_device(ctx, _ffi, orc)
+        cf = leg_corpus_files(ctx)
+        if cf is not None:
+            extras["configs"]["corpus_files"] = cf
     if rank == 0 and not a.no_moments:
-        # BASELINE config 4 itself: 4 x 100000 x 10000 f32 = 16 GB, generated on the device.
-        # One HBM pass per launch; algorithmic bytes = 4 B per param-draw.
-        mc, mn, mp = 4, 100000, 10000
-        try:
-            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
-        except _ffi.McrError:                      # a smaller device: quarter-size tensor
-            mp = 2500
-            big = ctx.alloc_tensor(mc, mn, mp, np.float32)
-        ctx.fill_synthetic(big, 4711)
-        ctx.moments(big)
-        ctx.profile(True)
-        ctx.profile_reset()
-        for _ in range(5):
-            mm, ms = ctx.moments(big)
-        pm = ctx.profile_get()["k_moments"]
-        ctx.profile(False)
-        big.free()
-        kms = pm["total_ms"] / pm["launches"]
-        sig = 10.0 ** ((np.arange(mp) % 7) - 3)
-        ok_m = bool(np.max(np.abs(mm - np.arange(mp)) / sig) < 0.05 and np.max(np.abs(ms / sig - 1)) < 0.05)
-        gbs = mc * mn * mp * 4 / (kms * 1e-3) / 1e9
-        moments = {"kernel": "k_moments_rows<float>", "workload": f"{mc}x{mn}x{mp} f32 ({mc * mn * mp * 4 / 1e9:.0f} GB) synthetic, on-device",
-                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s",
-                   "frac": gbs / HBM_PEAK_GBS, "frac_of_measured": (gbs / peak_measured) if peak_measured else None,
-                   "avg_launch_us": kms * 1e3, "param_draws_per_s": mc * mn * mp / (kms * 1e-3), "sane": ok_m,
-                   "traffic": None, "traffic_source": None}
-        tr = traffic_table().get("moments-4x100000x2500-f32")
-        if tr is not None and mp == 2500:
-            moments["traffic"], moments["traffic_source"] = tr.get("k_moments"), str(TRAFFIC_FILE.relative_to(ROOT))
+        from oracle import oracle as orc
+        # BASELINE config 4 itself: 4 x 100000 x 10000 f32 = 16 GB, generated on the device: the streaming-moments
+        # roofline (one HBM pass per launch, 4 B per param-draw) and, with the extras, the full pipeline on it.
+        moments, stress = leg_stress(_ffi, synth, orc, ctx.device, peak_measured, pipeline=bool(extras))
+        if stress is not None:
+            extras["configs"]["stress_pipeline"] = stress
+    if extras:
+        extras["extra_keys"] = sorted(["sync_call_us", "host_call_us", "call_latency", "d_sweep"] +
+                                      [f"configs.{k}" for k in extras["configs"]])
+        extras["extras_validated"] = bool(extras["call_latency"]["validated"] and all(d["validated"] for d in extras["d_sweep"])
+                                          and all(c["validated"] for c in extras["configs"].values()))
+    per_rank_ms = [x / a.steps * 1e3 for x in ranks.gather(statistics.median(ranks.own_secs))]
 
     if rank == 0:
         pd_step = C * N * P
@@ -525,6 +753,8 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
         kern = {}
         dom, dom_ms = None, -1.0
         ktraffic = traffic_table().get(f"{C}x{N}x{P}-{a.dtype}-{a.layout}", {})
+        if N <= 16384 and "k_acov_long" in prof:       # chains up to 16 384 draws: the tier-3 launch behind this HIP-event label is k_tier3
+            prof["k_tier3"] = prof.pop("k_acov_long")
         for name, r in prof.items():
             avg_ms = r["total_ms"] / max(r["launches"], 1)
             alg = alg_bytes(name, es)
@@ -572,7 +802,9 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
             "traffic_bytes_per_step": int(sum(v for k, v in ktraffic.items() if isinstance(v, (int, float)))) if ktraffic else None,
             "moments_roofline": moments,
             "cpu_baseline": cpu,
+            "ms_per_step_per_rank": [round(x, 5) for x in per_rank_ms],
         }
+        out.update(extras)
         print(json.dumps(out), flush=True)
     t.free()
     return 0 if valid else 1

@@ -107,11 +107,18 @@ const char* mcr_last_error(const mcr_ctx* ctx); /* ctx may be NULL: last mcr_ini
  * Default: MCR_WORKSPACE_MB env or 8192 MiB. */
 int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes);
 
-/* How many autocorrelation lags this context has re-derived the reference's way so far: the tier-3 scan of the ESS
- * lags (chains undecided at lag 256) takes no `rho < 0` decision (src/mcmc_ref/diagnostics.py:171-177) on an FFT /
- * tree-sum value within MCR_RHO_BAND (default 1e-10) of zero; such a lag is recomputed with _autocorr's own left-to-right
- * sums (diagnostics.py:180-193) first.  A diagnostic: tests use it to show that the guard ran.  Waits for the calls
- * in flight. */
+/* How the parameters of a call of this shape are cut into workspace chunks: parameters [k * n, (k + 1) * n) are
+ * processed together, n = *params_per_chunk (a function of the shape, the strides' layout class, the workspace limit and
+ * MCR_FFT).  The reference has no counterpart (its loop is per parameter, src/mcmc_ref/convert.py:140-147); tests and
+ * bench.py use it to put oracle-checked parameters on both sides of every chunk edge. */
+int mcr_plan_chunks(mcr_ctx* ctx, int64_t C, int64_t N, int64_t P, int64_t stride_c, int64_t stride_n, int64_t stride_p,
+                    int diagnostics, int64_t* params_per_chunk);
+
+/* How many autocorrelation lags this context has re-derived the reference's way so far: no tier of the ESS walk takes
+ * a `rho < 0` decision (src/mcmc_ref/diagnostics.py:171-177) on a value within MCR_RHO_BAND (default 1e-10) of zero --
+ * segment records + mean correction below lag 256, tree sums or FFTs beyond; such a lag is recomputed with _autocorr's
+ * own left-to-right sums and the chain's left-to-right mean (diagnostics.py:180-193) first.  A diagnostic: tests use it
+ * to show that the guard ran.  Waits for the calls in flight. */
 int mcr_rho_guard_count(mcr_ctx* ctx, int64_t* rederived);
 
 /* ---- device memory plumbing (for device-resident benchmarking and pipelines) --------- */

@@ -806,6 +806,36 @@ int check_common(mcr_ctx* ctx, const void* draws, int dtype, i64 C, i64 N, i64 P
     return MCR_OK;
 }
 
+// How a call of this shape is cut into workspace chunks of parameters (a pure function of the shape, the workspace limit
+// and MCR_FFT): shared by enqueue_impl and mcr_plan_chunks.
+struct ChunkPlan { bool ingest = false; WsPlan wp{}; FftPlan fp{}; size_t slack = 0; i64 pcmax = 0; };
+int plan_chunks(mcr_ctx* ctx, i64 C, i64 N, i64 P, i64 sc, i64 sn, i64 sp, bool do_diag, ChunkPlan& cp)
+{
+    const i64 M = C * N;
+    // tensors in the Arrow column layout [P][C][N] are consumed in place, f64 and f32 alike (the tile sort widens f32
+    // as it loads); anything else goes through one ingest pass into X[P][M] f64
+    cp.ingest = !((N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
+    cp.wp = plan_ws(M, (int)C, cp.ingest, false, N);
+    cp.fp = plan_fft(N, (int)C, do_diag && ctx->fft_on);
+    // the FFT tier is an accelerator, not a requirement: under a tight workspace limit it gets fewer slots, or none
+    // (the direct rounds then serve every listed pair), but at least a third of the limit stays with the parameters
+    while (cp.fp.on && cp.fp.bytes > ctx->ws_limit / 3) {
+        if (cp.fp.slots <= 1) { cp.fp = FftPlan{}; break; }
+        cp.fp.slots /= 2;
+        const size_t Nf = (size_t)1 << cp.fp.logN;
+        cp.fp.bytes = (size_t)cp.fp.slots * ((size_t)cp.fp.cb * Nf * 16 + Nf * 8 + Nf * 16) + 3 * 256;
+    }
+    cp.slack = 40 * 256 + cp.fp.bytes;
+    if (cp.wp.per_param + cp.slack > ctx->ws_limit)
+        return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace (%zu for the parameter + %zu shared, of which %zu "
+                    "for the FFT tier); limit is %zu", cp.wp.per_param + cp.slack, cp.wp.per_param, cp.slack, cp.fp.bytes, ctx->ws_limit);
+    i64 pcmax = (i64)((ctx->ws_limit - cp.slack) / cp.wp.per_param);
+    if (pcmax > P) pcmax = P;
+    if (pcmax > kMaxGridY / 2) pcmax = kMaxGridY / 2;   // k_acov_seg uses grid.z = 2 * pc
+    cp.pcmax = pcmax;
+    return MCR_OK;
+}
+
 int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i64 P, i64 sc, i64 sn, i64 sp,
                  int min_chains, const double* quantiles, int nq, const mcr_summary* out)
 {
@@ -828,34 +858,22 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     s.chunks.clear();
     s.trivial_nan = (M == 0 || P == 0);
     if (!s.trivial_nan) {
-        // tensors in the Arrow column layout [P][C][N] are consumed in place, f64 and f32 alike (the tile sort widens f32
-        // as it loads); anything else goes through one ingest pass into X[P][M] f64
-        const bool ingest = !((N <= 1 || sn == 1) && (C <= 1 || sc == N) && (P <= 1 || sp == M));
-        const WsPlan wp = plan_ws(M, (int)C, ingest, false, N);
         const bool do_diag_early = out->rhat || out->rhat_bulk || out->rhat_tail || out->ess_bulk || out->ess_tail ||
                                    out->lag_bulk || out->lag_tail;
-        FftPlan fp = plan_fft(N, (int)C, do_diag_early && ctx->fft_on);
-        // the FFT tier is an accelerator, not a requirement: under a tight workspace limit it gets fewer slots, or none
-        // (the direct rounds then serve every listed pair), but at least a third of the limit stays with the parameters
-        while (fp.on && fp.bytes > ctx->ws_limit / 3) {
-            if (fp.slots <= 1) { fp = FftPlan{}; break; }
-            fp.slots /= 2;
-            const size_t Nf = (size_t)1 << fp.logN;
-            fp.bytes = (size_t)fp.slots * ((size_t)fp.cb * Nf * 16 + Nf * 8 + Nf * 16) + 3 * 256;
-        }
+        ChunkPlan cp;
+        rc = plan_chunks(ctx, C, N, P, sc, sn, sp, do_diag_early, cp);
+        if (rc) return rc;
+        const bool ingest = cp.ingest;
+        const WsPlan& wp = cp.wp;
+        const FftPlan& fp = cp.fp;
+        const size_t slack = cp.slack;
+        const i64 pcmax = cp.pcmax;
         double2 *tw1 = nullptr, *tw2 = nullptr;
         if (fp.on) {
             rc = get_twiddles(ctx, 1 << fp.log1, &tw1);
             if (!rc) rc = get_twiddles(ctx, 1 << fp.log2, &tw2);
             if (rc) return rc;
         }
-        const size_t slack = 40 * 256 + fp.bytes;
-        if (wp.per_param + slack > ctx->ws_limit)
-            return fail(ctx, MCR_ENOMEM, "one parameter needs %zu bytes of workspace (%zu for the parameter + %zu shared, of which %zu "
-                        "for the FFT tier); limit is %zu", wp.per_param + slack, wp.per_param, slack, fp.bytes, ctx->ws_limit);
-        i64 pcmax = (i64)((ctx->ws_limit - slack) / wp.per_param);
-        if (pcmax > P) pcmax = P;
-        if (pcmax > kMaxGridY / 2) pcmax = kMaxGridY / 2;   // k_acov_seg uses grid.z = 2 * pc
         rc = ensure_ws(ctx, (size_t)pcmax * wp.per_param + slack);
         if (rc) return rc;
         const int R = res_fields(nq);
@@ -1168,6 +1186,18 @@ int mcr_set_workspace_limit(mcr_ctx* ctx, size_t bytes)
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
     if (bytes < (1u << 20)) return fail(ctx, MCR_EINVAL, "workspace limit must be at least 1 MiB");
     ctx->ws_limit = bytes;
+    return MCR_OK;
+}
+
+int mcr_plan_chunks(mcr_ctx* ctx, int64_t C, int64_t N, int64_t P, int64_t sc, int64_t sn, int64_t sp, int diagnostics,
+                    int64_t* params_per_chunk)
+{
+    if (!ctx || !params_per_chunk) return fail(ctx, MCR_EINVAL, "mcr_plan_chunks: NULL argument");
+    if (C <= 0 || N <= 0 || P <= 0) { *params_per_chunk = 0; return MCR_OK; }
+    ChunkPlan cp;
+    const int rc = plan_chunks(ctx, C, N, P, sc, sn, sp, diagnostics != 0, cp);
+    if (rc) return rc;
+    *params_per_chunk = cp.pcmax;
     return MCR_OK;
 }
 

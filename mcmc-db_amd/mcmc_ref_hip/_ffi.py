@@ -73,6 +73,7 @@ SYMBOLS = {
     "mcr_last_error": (C.c_char_p, [C.c_void_p]),
     "mcr_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mcr_rho_guard_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mcr_plan_chunks": (C.c_int, [C.c_void_p] + [C.c_int64] * 6 + [C.c_int, C.POINTER(C.c_int64)]),
     "mcr_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mcr_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -476,6 +477,13 @@ class Context:
         return cov[:P, :P] if P else np.empty((0, 0))
 
     # -- measurement -----------------------------------------------------------------------------
+    def params_per_chunk(self, t: "DeviceTensor", diagnostics: bool = True) -> int:
+        """Parameters per workspace chunk of a call on this tensor (mcr_plan_chunks): chunk k is [k * n, (k + 1) * n)."""
+        _, C_, N, P, sc, sn, sp = t.targs
+        v = C.c_int64(0)
+        self._check(self.lib.mcr_plan_chunks(self.handle, C_, N, P, sc, sn, sp, int(diagnostics), C.byref(v)))
+        return int(v.value)
+
     def rho_guard_count(self) -> int:
         """Band lags of the tier-3 ESS scan re-derived with the reference's own sums so far (mcr_rho_guard_count)."""
         v = C.c_int64(0)

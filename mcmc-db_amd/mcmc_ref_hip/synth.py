@@ -60,3 +60,29 @@ def c1_model(C: int = 4, N: int = 10000, P: int = 100, seed: int = 4711, params=
                 x = np.round(x, 2)
             out[k, c] = x
     return out.astype(dtype, copy=False)
+
+
+def stress_check_sample(P: int, per_chunk: int, count: int = 128) -> np.ndarray:
+    """Which parameters of a large tensor (the stress shape: mu_p = p, sigma_p = 10**((p mod 7) - 3), f32) a test or bench.py re-computes on the host:
+
+    * the first and the last parameter of EVERY workspace chunk (per_chunk = Context.params_per_chunk: chunk k is
+      [k * per_chunk, (k + 1) * per_chunk)), i.e. both sides of every chunk edge;
+    * every residue of p mod 7 (the generator's seven scales) at the low and at the high end of the tensor;
+    * at least eight parameters whose sigma is at or below the f32 grid at mu_p (p >= 4096 with p mod 7 == 0: sigma = 1e-3
+      against a grid step of 4.9e-4 .. 9.8e-4, so the 400 000 draws take a handful of distinct values: all ties);
+    * an even spread over the tensor for the rest, `count` parameters in all (fewer if P is smaller)."""
+    per_chunk = max(int(per_chunk), 1)
+    sel = set()
+    for p0 in range(0, P, per_chunk):
+        sel.add(p0)
+        sel.add(min(p0 + per_chunk, P) - 1)
+    sel.update(range(min(7, P)))
+    sel.update(range(max(P - 7, 0), P))
+    tied = [p for p in range(P - 1, 4095, -1) if p % 7 == 0]
+    sel.update(tied[:: max(len(tied) // 8, 1)][:10])
+    want = min(count, P)
+    if len(sel) < want:                         # an even spread over the parameters not chosen yet
+        rest = np.array([p for p in range(P) if p not in sel])
+        need = want - len(sel)
+        sel.update(int(p) for p in rest[((np.arange(need) + 0.5) * len(rest) / need).astype(int)])
+    return np.array(sorted(sel), dtype=np.int64)

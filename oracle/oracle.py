@@ -189,3 +189,19 @@ def summarize(draws: np.ndarray, layout: str = "pcn", min_chains: int = 4,
     out["q"] = arrs["q"][:P * nq].reshape(P, nq).copy()
     out["lag_bulk"] = lb[:P].copy(); out["lag_tail"] = lt[:P].copy()
     return out
+
+
+def summarize_mt(draws: np.ndarray, layout: str = "pcn", threads: int | None = None, **kw) -> dict:
+    """`summarize` with the parameters split over host threads (ctypes releases the GIL; parameters are independent)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    ax = layout.index("p")
+    P = draws.shape[ax]
+    T = max(1, min(threads or (os.cpu_count() or 1), P))
+    if T == 1:
+        return summarize(draws, layout, **kw)
+    cuts = [P * i // T for i in range(T + 1)]
+    parts = [np.ascontiguousarray(np.take(draws, range(cuts[i], cuts[i + 1]), axis=ax)) for i in range(T)]
+    with ThreadPoolExecutor(T) as pool:
+        outs = list(pool.map(lambda x: summarize(x, layout, **kw), parts))
+    return {k: np.concatenate([o[k] for o in outs], axis=0) for k in outs[0]}

@@ -4,8 +4,9 @@ workspace; f32 tensors are sorted as packed records, csrc/mcr_sort32.hpp), check
 
   * size-independent properties over every parameter (the generator's location / scale, ordered quantiles, median ==
     q50, 0 < ESS <= M, rhat = max(bulk, tail) < 1.01 for iid draws, non-negative integer lags), and
-  * the oracle (the reference's algorithm, oracle/mcr_oracle.c) on 16 parameters spread over the tensor: integer
-    outputs exact, floats to 1e-9.
+  * the oracle (the reference's algorithm, oracle/mcr_oracle.c) on 128 parameters -- the first and last parameter of every
+    workspace chunk, every scale of the generator, the all-ties parameters at the f32 grid -- integer outputs exact, floats
+    to 1e-9.
 
 The reference itself is fp64-only and has no golden for this shape; parity is against the oracle on the widened draws."""
 from __future__ import annotations
@@ -49,12 +50,21 @@ def test_config4_full_size_all_parameters(oracle, monkeypatch):
             assert np.all(got["rhat"] >= got["rhat_bulk"]) and np.all(got["rhat"] >= got["rhat_tail"])
             assert np.all(got["rhat"] < 1.01)                                   # iid chains
             assert np.all(got["lag_bulk"] >= 0) and np.all(got["lag_tail"] >= 0)
-            # parameters the f32 grid cannot resolve are all ties: still exact ranks, checked through the oracle below
-            sel = np.unique(np.concatenate([np.linspace(0, P - 1, 12).astype(int), [6, 9996, 9997, 9999]]))
+            # the oracle on 128 parameters: both sides of every workspace-chunk edge, every scale of the generator,
+            # >= 8 parameters whose sigma is at the f32 grid (all ties: still exact ranks) -- synth.stress_check_sample
+            from mcmc_ref_hip import synth
+            per_chunk = ctx.params_per_chunk(t)
+            assert 0 < per_chunk < P                        # the 16 GB tensor does stream through the workspace in chunks
+            sel = synth.stress_check_sample(P, per_chunk, 128)
+            edges = set(range(0, P, per_chunk)) | {min(p0 + per_chunk, P) - 1 for p0 in range(0, P, per_chunk)}
+            assert len(sel) >= 128 and edges <= set(sel.tolist()) and {int(p) % 7 for p in sel} == set(range(7))
             sub = np.stack([_row(ctx, t, int(i), M) for i in sel]).reshape(len(sel), Cn, N)
+            grid = np.spacing(sel.astype(np.float32)).astype(np.float64)
+            n_tied = sum(len(np.unique(sub[k])) < 64 for k in range(len(sel)) if 10.0 ** ((sel[k] % 7) - 3) <= 2.1 * grid[k])
+            assert n_tied >= 8, n_tied
         finally:
             t.free()
-    exp = oracle.summarize(sub, "pcn")
+    exp = oracle.summarize_mt(sub, "pcn")
     for k in ("lag_bulk", "lag_tail"):
         assert np.array_equal(got[k][sel], exp[k]), k
     assert np.array_equal(got["q"][sel], exp["q"]) and np.array_equal(got["median"][sel], exp["median"])
