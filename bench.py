@@ -461,7 +461,14 @@ def leg_corpus_files(ctx) -> dict | None:
         return None
     res = parquet.summarize_files(ctx, paths, min_chains=4)
     ms, all_ms = _median_ms(lambda: parquet.summarize_files(ctx, paths, min_chains=4), 9, ctx.sync)
-    c_ms, c_all = _median_ms(lambda: parquet._summarize_paths(ctx, [str(p) for p in paths], 4, [0.05, 0.5, 0.95], True), 9, ctx.sync)
+    runs = []
+
+    def c_call():
+        ph = {}
+        parquet._summarize_paths(ctx, [str(p) for p in paths], 4, [0.05, 0.5, 0.95], True, ph)
+        runs.append(ph)
+    c_ms, c_all = _median_ms(c_call, 9, ctx.sync)
+    phases = {k: round(statistics.median(r[k] for r in runs), 3) for k in runs[0]}
     res = parquet.summarize_files(ctx, paths, min_chains=4)
     n_vals, worst, total_pd = 0, 0.0, 0
     for path, got in zip(paths, res):
@@ -476,7 +483,7 @@ def leg_corpus_files(ctx) -> dict | None:
                         "(BASELINE config 2 end to end)",
             "ms_end_to_end": round(ms, 3), "ms_min": round(min(all_ms), 3), "param_draws": total_pd,
             "param_draws_per_s": total_pd / (ms * 1e-3),
-            "ms_c_call_only": round(c_ms, 3),
+            "ms_c_call_only": round(c_ms, 3), "phases_ms": phases,
             "goldens_checked": n_vals, "max_rel_err_vs_packaged_goldens": worst,
             "validated": bool(n_vals >= 1300 and worst <= 1e-6),
             "validation": "rhat / ess_bulk / ess_tail of every parameter against the reference's own meta.json goldens (<= 1e-6)"}

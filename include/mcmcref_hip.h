@@ -340,6 +340,28 @@ int64_t mcr_fileset_chains(const mcr_fileset* fs, int file);
 int64_t mcr_fileset_draws(const mcr_fileset* fs, int file); /* draws per chain (of the first chain when they differ) */
 const char* mcr_fileset_param_name(const mcr_fileset* fs, int file, int64_t param);
 const double* mcr_fileset_field(const mcr_fileset* fs, int file, int field); /* P doubles (MCR_FS_Q: P * n_q) */
+/* The whole set in two blocks, for callers that turn it into dictionaries (the shape reference.stats /
+ * diagnostics_for_model return, src/mcmc_ref/reference.py:30-104) without a call per file and field:
+ * mcr_fileset_export writes one row of 10 + n_q doubles per parameter, files and parameters in order -- mean, std,
+ * median, rhat, ess_bulk, ess_tail, rhat_bulk, rhat_tail, lag_bulk, lag_tail, q[0 .. n_q) -- and returns the number of
+ * rows of the set (at most cap_rows are written; rows may be NULL to ask); mcr_fileset_names writes the parameters'
+ * names in the same order, each terminated by NUL, and returns the bytes that takes (written only if they fit cap). */
+int64_t mcr_fileset_export(const mcr_fileset* fs, double* rows, int64_t cap_rows);
+int64_t mcr_fileset_names(const mcr_fileset* fs, char* buf, int64_t cap);
+/* Where the host-clock time of the mcr_summarize_files call that built `fs` went, in milliseconds (the path it replaces,
+ * pq.read_table + the per-parameter loops of src/mcmc_ref/store.py:79-95 / reference.py:30-104, is host-bound, so the
+ * split is part of the measurement): ms[MCR_FS_PH_*]; returns MCR_FS_PHASES (at most `cap` entries are written). */
+#define MCR_FS_PH_OPEN 0    /* open + fstat of every file, staging buffers */
+#define MCR_FS_PH_READ 1    /* MCR_IO_THREADS host threads (default 8): pread of the whole file images into pinned memory,
+                               footer + page-header parse from there; uploads issued behind them in >= 2 MB pieces */
+#define MCR_FS_PH_PLAN 2    /* request list, page table, table uploads */
+#define MCR_FS_PH_DECODE 3  /* wait for the uploads + Snappy / page decode kernels + the chain / draw layout kernel */
+#define MCR_FS_PH_STATS 4   /* the statistics pipeline of every job (enqueue, kernels, result copies) */
+#define MCR_FS_PH_COLLECT 5 /* results into the set */
+#define MCR_FS_PH_CLOSE 6   /* close, free of the parsed metadata */
+#define MCR_FS_PH_TOTAL 7
+#define MCR_FS_PHASES 8
+int mcr_fileset_phases(const mcr_fileset* fs, double* ms, int cap);
 void mcr_fileset_free(mcr_fileset* fs);
 
 #ifdef __cplusplus

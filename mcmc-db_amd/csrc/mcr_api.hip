@@ -15,8 +15,11 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
+#include <chrono>
 #include <exception>
 #include <memory>
+#include <thread>
 #include <string>
 #include <functional>
 #include <new>
@@ -97,6 +100,9 @@ struct mcr_ctx {
     void* pq_scratch = nullptr; size_t pq_scratch_bytes = 0;
     void* pq_tab = nullptr; size_t pq_tab_bytes = 0;
     void* fs_arena = nullptr; size_t fs_arena_bytes = 0;   // mcr_summarize_files: decoded draws + chain / draw ids
+    void* pq_pin = nullptr; size_t pq_pin_bytes = 0;       // mcr_summarize_files: pinned host staging of the files' column chunks
+    int io_threads = 8;                                    // MCR_IO_THREADS: host threads that read the file images and parse their footers
+    size_t io_piece = (size_t)2 << 20;                     // MCR_IO_PIECE_KB: the finished prefix is uploaded in pieces of at least this size
     // z tables (k_ztable): a function of M alone, so they are computed once per pooled length and kept for the life of
     // the context instead of being relaunched by every call (most recently used first; a handful of shapes is typical)
     struct ZTab { i64 M; double* tab; };
@@ -1103,6 +1109,14 @@ int mcr_init(int device, mcr_ctx** out)
         const int v = atoi(env);
         ctx->n_lanes = v < 1 ? 1 : (v > MCR_MAX_INFLIGHT ? MCR_MAX_INFLIGHT : v);
     }
+    if (const char* env = getenv("MCR_IO_PIECE_KB")) {
+        const long v = atol(env);
+        ctx->io_piece = (size_t)(v < 64 ? 64 : (v > (1 << 20) ? (1 << 20) : v)) << 10;
+    }
+    if (const char* env = getenv("MCR_IO_THREADS")) {
+        const int v = atoi(env);
+        ctx->io_threads = v < 1 ? 1 : (v > 64 ? 64 : v);
+    }
     e = hipSetDevice(device);
     for (int l = 0; l < ctx->n_lanes && e == hipSuccess; ++l)
         e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
@@ -1165,6 +1179,7 @@ void mcr_free(mcr_ctx* ctx)
     if (ctx->pq_scratch) hipFree(ctx->pq_scratch);
     if (ctx->pq_tab) hipFree(ctx->pq_tab);
     if (ctx->fs_arena) hipFree(ctx->fs_arena);
+    if (ctx->pq_pin) hipHostFree(ctx->pq_pin);
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
@@ -1987,137 +2002,201 @@ int mcr_parquet_page_info(const mcr_parquet* f, int page, int64_t* info)
     return MCR_OK;
 }
 
-int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs)
+namespace {
+// A batched decode in three steps: pq_plan (host only: byte spans to stage, page table), pq_buffers (device buffers +
+// table uploads), pq_launch (the two kernels).  Between buffers and launch the caller stages the spans' file bytes at
+// pq_stage + span.stage_off: mcr_parquet_decode copies them from the caller's file image (pageable memory),
+// mcr_summarize_files reads them into pinned memory on host threads and uploads behind them.
+struct PqSpan { const mcr::pq::File* f; u64 start, end; size_t stage_off; };
+struct PqPlan {
+    std::vector<PqSpan> merged;
+    size_t stage_total = 0, scratch_total = 0;
+    std::vector<mcr::pq::PageDev> tab;
+    std::vector<int> l_snappy, l_decode;
+    mcr::pq::PageDev* d_tab = nullptr; int* d_ls = nullptr; int* d_ld = nullptr; int* d_err = nullptr;
+};
+
+// whole_files: (file, offset of its whole image in the staging buffer) sorted by file pointer, and the total staged
+// bytes -- the caller stages whole file images instead of the packed column chunks (mcr_summarize_files, which wants
+// nearly every byte of every file anyway and starts uploading before the footers are parsed).
+using FileBase = std::pair<const mcr::pq::File*, size_t>;
+int pq_plan(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs, PqPlan& P,
+            const std::vector<FileBase>* whole_files = nullptr, size_t whole_total = 0)
 {
     namespace pq = mcr::pq;
+    std::vector<PqSpan> spans;
+    std::vector<pq::PageDev>& tab = P.tab;
+    // 1. byte spans to upload: the column chunks of the requested columns, merged when (nearly) adjacent
+    for (int r = 0; r < n_reqs; ++r) {
+        const mcr_parquet_request& q = reqs[r];
+        if (!q.file) return fail(ctx, MCR_EINVAL, "request %d: file is NULL", r);
+        const pq::File& f = q.file->f;
+        if (q.column < 0 || q.column >= (int)f.cols.size()) return fail(ctx, MCR_EINVAL, "request %d: column %d out of range", r, q.column);
+        const pq::Column& col = f.cols[q.column];
+        if (col.type != pq::T_INT32 && col.type != pq::T_INT64 && col.type != pq::T_FLOAT && col.type != pq::T_DOUBLE)
+            return fail(ctx, MCR_EINVAL, "parquet: column '%s' has physical type %d; only INT32, INT64, FLOAT and DOUBLE columns are decoded", col.name.c_str(), col.type);
+        if (q.out_kind != MCR_PQ_F64 && q.out_kind != MCR_PQ_I64) return fail(ctx, MCR_EINVAL, "request %d: bad out_kind %d", r, q.out_kind);
+        if (q.out_kind == MCR_PQ_I64 && col.type != pq::T_INT32 && col.type != pq::T_INT64)
+            return fail(ctx, MCR_EINVAL, "parquet: column '%s' is not an integer column", col.name.c_str());
+        if (f.num_rows > 0 && !q.out_dev) return fail(ctx, MCR_EINVAL, "request %d: out_dev is NULL", r);
+        for (const pq::Chunk& ch : f.chunks)
+            if (ch.col == q.column && ch.end > ch.start) spans.push_back(PqSpan{&f, ch.start, ch.end, 0});
+    }
+    std::sort(spans.begin(), spans.end(), [](const PqSpan& a, const PqSpan& b) {
+        return a.f != b.f ? std::less<const pq::File*>()(a.f, b.f) : a.start < b.start; });
+    std::vector<PqSpan>& merged = P.merged;
+    for (const PqSpan& s : spans) {
+        if (!merged.empty() && merged.back().f == s.f && s.start <= merged.back().end + 4096) {
+            if (s.end > merged.back().end) merged.back().end = s.end;
+        } else merged.push_back(s);
+    }
+    size_t stage_total = 0;
+    if (whole_files) {
+        for (PqSpan& s : merged) {
+            auto it = std::lower_bound(whole_files->begin(), whole_files->end(), s.f, [](const FileBase& a, const mcr::pq::File* key) {
+                return std::less<const mcr::pq::File*>()(a.first, key); });
+            if (it == whole_files->end() || it->first != s.f) return fail(ctx, MCR_EINVAL, "parquet: request on a file that is not staged");
+            s.stage_off = it->second + (size_t)s.start;
+        }
+        stage_total = whole_total;
+    } else {
+        for (PqSpan& s : merged) { s.stage_off = align_up(stage_total, 256); stage_total = s.stage_off + (size_t)(s.end - s.start); }
+    }
+    P.stage_total = stage_total;
+    // staged position of the file bytes [off, off + n): the WHOLE payload must lie inside one uploaded span
+    // (spans are sorted by (file, start): binary search for the file's first span, then a short walk)
+    auto stage_of = [&](const pq::File* f, u64 off, u64 n) -> size_t {
+        auto it = std::lower_bound(merged.begin(), merged.end(), f, [](const PqSpan& s, const pq::File* key) {
+            return std::less<const pq::File*>()(s.f, key); });
+        for (; it != merged.end() && it->f == f; ++it)
+            if (off >= it->start && off + n <= it->end) return it->stage_off + (size_t)(off - it->start);
+        return (size_t)-1;
+    };
+    // 2. page table
+    size_t scratch_total = 0;
+    for (int r = 0; r < n_reqs; ++r) {
+        const mcr_parquet_request& q = reqs[r];
+        const pq::File& f = q.file->f;
+        const pq::Column& col = f.cols[q.column];
+        const u32 es = (col.type == pq::T_INT64 || col.type == pq::T_DOUBLE) ? 8 : 4;
+        for (const pq::Chunk& ch : f.chunks) {
+            if (ch.col != q.column) continue;
+            int dict_idx = -1;
+            for (int k = 0; k < ch.n_pages; ++k) {
+                const pq::Page& pg = f.pages[(size_t)ch.first_page + k];
+                if (pg.codec != pq::CODEC_NONE && pg.codec != pq::CODEC_SNAPPY)
+                    return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses compression codec %d; only UNCOMPRESSED and SNAPPY are decoded", col.name.c_str(), pg.codec);
+                pq::PageDev d; memset(&d, 0, sizeof(d));
+                const bool v2 = pg.kind == pq::PAGE_DATA_V2;
+                const u32 lvl = v2 ? pg.rep_bytes + pg.def_bytes : 0;
+                const bool comp = pg.codec == pq::CODEC_SNAPPY && (!v2 || pg.v2_compressed);
+                if (pg.uncomp_size < lvl) return fail(ctx, MCR_EINVAL, "parquet: v2 page smaller than its levels");
+                d.src_off = stage_of(&f, pg.payload_off, pg.comp_size);
+                if (pg.comp_size > 0 && d.src_off == (u64)(size_t)-1) return fail(ctx, MCR_EINVAL, "parquet: page outside its column chunk");
+                d.comp_size = pg.comp_size - lvl; d.uncomp_size = pg.uncomp_size - lvl;
+                d.num_values = pg.num_values; d.lvl_bytes = lvl; d.def_bytes = v2 ? pg.def_bytes : 0;
+                d.kind = (unsigned char)pg.kind; d.compressed = comp ? 1 : 0; d.phys_type = (unsigned char)col.type;
+                d.max_def = (unsigned char)((v2 && pg.def_bytes == 0) ? 0 : col.max_def);   // v2 without level bytes: all defined
+                d.out_kind = (unsigned char)q.out_kind;
+                d.dict_page = -1;
+                if (v2 && pg.rep_bytes) return fail(ctx, MCR_EINVAL, "parquet: repetition levels in a flat column");
+                if (!comp && d.comp_size != d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: uncompressed page with differing sizes");
+                if (comp) { d.dst_off = align_up(scratch_total, 16); scratch_total = (size_t)d.dst_off + d.uncomp_size + 16; }
+                if (pg.kind == pq::PAGE_DICT) {
+                    if (pg.encoding != pq::ENC_PLAIN && pg.encoding != pq::ENC_PLAIN_DICT)
+                        return fail(ctx, MCR_EINVAL, "parquet: dictionary page encoding %d is not supported", pg.encoding);
+                    if ((u64)pg.num_values * es > d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: dictionary page shorter than its entries");
+                    d.encoding = pq::ENC_PLAIN;
+                    dict_idx = (int)tab.size();
+                } else {
+                    if (pg.encoding == pq::ENC_PLAIN) d.encoding = pq::ENC_PLAIN;
+                    else if (pg.encoding == pq::ENC_RLE_DICT || pg.encoding == pq::ENC_PLAIN_DICT) {
+                        if (pg.dict < 0 || dict_idx < 0) return fail(ctx, MCR_EINVAL, "parquet: dictionary-encoded page without a dictionary page");
+                        d.encoding = pq::ENC_RLE_DICT; d.dict_page = dict_idx; d.dict_count = pg.dict_count;
+                    } else
+                        return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses value encoding %d; only PLAIN and RLE_DICTIONARY are decoded", col.name.c_str(), pg.encoding);
+                    d.out = q.out_dev; d.out_off = pg.row_off;
+                    P.l_decode.push_back((int)tab.size());
+                }
+                if (comp) P.l_snappy.push_back((int)tab.size());
+                tab.push_back(d);
+            }
+        }
+    }
+    P.scratch_total = scratch_total;
+    return MCR_OK;
+}
+
+// 3. device buffers + the page table and the two page lists, on ctx->stream
+int pq_buffers(mcr_ctx* ctx, PqPlan& P)
+{
+    namespace pq = mcr::pq;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_buf(ctx, &ctx->pq_stage, &ctx->pq_stage_bytes, P.stage_total + pq::kInWin + 256);
+    if (rc) return rc;
+    rc = ensure_buf(ctx, &ctx->pq_scratch, &ctx->pq_scratch_bytes, P.scratch_total + 256);
+    if (rc) return rc;
+    const size_t tab_bytes = align_up(P.tab.size() * sizeof(pq::PageDev), 256);
+    const size_t ls_bytes = align_up(P.l_snappy.size() * 4 + 4, 256), ld_bytes = align_up(P.l_decode.size() * 4 + 4, 256);
+    rc = ensure_buf(ctx, &ctx->pq_tab, &ctx->pq_tab_bytes, tab_bytes + ls_bytes + ld_bytes + 256);
+    if (rc) return rc;
+    char* tb = (char*)ctx->pq_tab;
+    P.d_tab = (pq::PageDev*)tb;
+    P.d_ls = (int*)(tb + tab_bytes); P.d_ld = (int*)(tb + tab_bytes + ls_bytes);
+    P.d_err = (int*)(tb + tab_bytes + ls_bytes + ld_bytes);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync((char*)ctx->pq_stage + P.stage_total, 0, pq::kInWin + 256, st));
+    if (!P.tab.empty()) HIP_TRY(ctx, hipMemcpyAsync(P.d_tab, P.tab.data(), P.tab.size() * sizeof(pq::PageDev), hipMemcpyHostToDevice, st));
+    if (!P.l_snappy.empty()) HIP_TRY(ctx, hipMemcpyAsync(P.d_ls, P.l_snappy.data(), P.l_snappy.size() * 4, hipMemcpyHostToDevice, st));
+    if (!P.l_decode.empty()) HIP_TRY(ctx, hipMemcpyAsync(P.d_ld, P.l_decode.data(), P.l_decode.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(P.d_err, 0, 8, st));
+    return MCR_OK;
+}
+
+int pq_launch(mcr_ctx* ctx, const PqPlan& P)
+{
+    namespace pq = mcr::pq;
+    if (!P.l_snappy.empty())
+        LAUNCH(ctx, K_PQ_SNAPPY, pq::k_pq_snappy, dim3((unsigned)P.l_snappy.size()), dim3(64), 0, (const unsigned char*)ctx->pq_stage,
+               (unsigned char*)ctx->pq_scratch, (const pq::PageDev*)P.d_tab, (const int*)P.d_ls, P.d_err);
+    if (!P.l_decode.empty())
+        LAUNCH(ctx, K_PQ_DECODE, pq::k_pq_decode, dim3((unsigned)P.l_decode.size()), dim3(256), 0, (const unsigned char*)ctx->pq_stage,
+               (const unsigned char*)ctx->pq_scratch, (const pq::PageDev*)P.d_tab, (const int*)P.d_ld, P.d_err);
+    return MCR_OK;
+}
+
+int pq_error(mcr_ctx* ctx, const int* h_err)
+{
+    if (!h_err[0]) return MCR_OK;
+    static const char* const what[] = {"", "corrupt Snappy stream", "null values are not supported", "corrupt definition levels",
+                                       "corrupt RLE / bit-packed runs", "dictionary index out of range", "page shorter than its values"};
+    const int c = h_err[0];
+    return fail(ctx, MCR_EINVAL, "parquet: %s (page %d of the request)", (c > 0 && c < 7) ? what[c] : "decode error", h_err[1]);
+}
+}  // namespace
+
+int mcr_parquet_decode(mcr_ctx* ctx, const mcr_parquet_request* reqs, int n_reqs)
+{
     if (!ctx) return fail(nullptr, MCR_EINVAL, "ctx is NULL");
     if (n_reqs < 0 || (n_reqs > 0 && !reqs)) return fail(ctx, MCR_EINVAL, "bad request list");
     if (n_reqs == 0) return MCR_OK;
-    struct Span { const pq::File* f; u64 start, end; size_t stage_off; };
-    std::vector<Span> spans;
-    std::vector<pq::PageDev> tab;
-    std::vector<int> l_snappy, l_decode;
     try {
-        // 1. byte spans to upload: the column chunks of the requested columns, merged when (nearly) adjacent
-        for (int r = 0; r < n_reqs; ++r) {
-            const mcr_parquet_request& q = reqs[r];
-            if (!q.file) return fail(ctx, MCR_EINVAL, "request %d: file is NULL", r);
-            const pq::File& f = q.file->f;
-            if (q.column < 0 || q.column >= (int)f.cols.size()) return fail(ctx, MCR_EINVAL, "request %d: column %d out of range", r, q.column);
-            const pq::Column& col = f.cols[q.column];
-            if (col.type != pq::T_INT32 && col.type != pq::T_INT64 && col.type != pq::T_FLOAT && col.type != pq::T_DOUBLE)
-                return fail(ctx, MCR_EINVAL, "parquet: column '%s' has physical type %d; only INT32, INT64, FLOAT and DOUBLE columns are decoded", col.name.c_str(), col.type);
-            if (q.out_kind != MCR_PQ_F64 && q.out_kind != MCR_PQ_I64) return fail(ctx, MCR_EINVAL, "request %d: bad out_kind %d", r, q.out_kind);
-            if (q.out_kind == MCR_PQ_I64 && col.type != pq::T_INT32 && col.type != pq::T_INT64)
-                return fail(ctx, MCR_EINVAL, "parquet: column '%s' is not an integer column", col.name.c_str());
-            if (f.num_rows > 0 && !q.out_dev) return fail(ctx, MCR_EINVAL, "request %d: out_dev is NULL", r);
-            for (const pq::Chunk& ch : f.chunks)
-                if (ch.col == q.column && ch.end > ch.start) spans.push_back(Span{&f, ch.start, ch.end, 0});
-        }
-        std::sort(spans.begin(), spans.end(), [](const Span& a, const Span& b) {
-            return a.f != b.f ? std::less<const pq::File*>()(a.f, b.f) : a.start < b.start; });
-        std::vector<Span> merged;
-        for (const Span& s : spans) {
-            if (!merged.empty() && merged.back().f == s.f && s.start <= merged.back().end + 4096) {
-                if (s.end > merged.back().end) merged.back().end = s.end;
-            } else merged.push_back(s);
-        }
-        size_t stage_total = 0;
-        for (Span& s : merged) { s.stage_off = align_up(stage_total, 256); stage_total = s.stage_off + (size_t)(s.end - s.start); }
-        // staged position of the file bytes [off, off + n): the WHOLE payload must lie inside one uploaded span
-        auto stage_of = [&](const pq::File* f, u64 off, u64 n) -> size_t {
-            for (const Span& s : merged) if (s.f == f && off >= s.start && off + n <= s.end) return s.stage_off + (size_t)(off - s.start);
-            return (size_t)-1;
-        };
-        // 2. page table
-        size_t scratch_total = 0;
-        for (int r = 0; r < n_reqs; ++r) {
-            const mcr_parquet_request& q = reqs[r];
-            const pq::File& f = q.file->f;
-            const pq::Column& col = f.cols[q.column];
-            const u32 es = (col.type == pq::T_INT64 || col.type == pq::T_DOUBLE) ? 8 : 4;
-            for (const pq::Chunk& ch : f.chunks) {
-                if (ch.col != q.column) continue;
-                int dict_idx = -1;
-                for (int k = 0; k < ch.n_pages; ++k) {
-                    const pq::Page& pg = f.pages[(size_t)ch.first_page + k];
-                    if (pg.codec != pq::CODEC_NONE && pg.codec != pq::CODEC_SNAPPY)
-                        return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses compression codec %d; only UNCOMPRESSED and SNAPPY are decoded", col.name.c_str(), pg.codec);
-                    pq::PageDev d; memset(&d, 0, sizeof(d));
-                    const bool v2 = pg.kind == pq::PAGE_DATA_V2;
-                    const u32 lvl = v2 ? pg.rep_bytes + pg.def_bytes : 0;
-                    const bool comp = pg.codec == pq::CODEC_SNAPPY && (!v2 || pg.v2_compressed);
-                    if (pg.uncomp_size < lvl) return fail(ctx, MCR_EINVAL, "parquet: v2 page smaller than its levels");
-                    d.src_off = stage_of(&f, pg.payload_off, pg.comp_size);
-                    if (pg.comp_size > 0 && d.src_off == (u64)(size_t)-1) return fail(ctx, MCR_EINVAL, "parquet: page outside its column chunk");
-                    d.comp_size = pg.comp_size - lvl; d.uncomp_size = pg.uncomp_size - lvl;
-                    d.num_values = pg.num_values; d.lvl_bytes = lvl; d.def_bytes = v2 ? pg.def_bytes : 0;
-                    d.kind = (unsigned char)pg.kind; d.compressed = comp ? 1 : 0; d.phys_type = (unsigned char)col.type;
-                    d.max_def = (unsigned char)((v2 && pg.def_bytes == 0) ? 0 : col.max_def);   // v2 without level bytes: all defined
-                    d.out_kind = (unsigned char)q.out_kind;
-                    d.dict_page = -1;
-                    if (v2 && pg.rep_bytes) return fail(ctx, MCR_EINVAL, "parquet: repetition levels in a flat column");
-                    if (!comp && d.comp_size != d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: uncompressed page with differing sizes");
-                    if (comp) { d.dst_off = align_up(scratch_total, 16); scratch_total = (size_t)d.dst_off + d.uncomp_size + 16; }
-                    if (pg.kind == pq::PAGE_DICT) {
-                        if (pg.encoding != pq::ENC_PLAIN && pg.encoding != pq::ENC_PLAIN_DICT)
-                            return fail(ctx, MCR_EINVAL, "parquet: dictionary page encoding %d is not supported", pg.encoding);
-                        if ((u64)pg.num_values * es > d.uncomp_size) return fail(ctx, MCR_EINVAL, "parquet: dictionary page shorter than its entries");
-                        d.encoding = pq::ENC_PLAIN;
-                        dict_idx = (int)tab.size();
-                    } else {
-                        if (pg.encoding == pq::ENC_PLAIN) d.encoding = pq::ENC_PLAIN;
-                        else if (pg.encoding == pq::ENC_RLE_DICT || pg.encoding == pq::ENC_PLAIN_DICT) {
-                            if (pg.dict < 0 || dict_idx < 0) return fail(ctx, MCR_EINVAL, "parquet: dictionary-encoded page without a dictionary page");
-                            d.encoding = pq::ENC_RLE_DICT; d.dict_page = dict_idx; d.dict_count = pg.dict_count;
-                        } else
-                            return fail(ctx, MCR_EINVAL, "parquet: column '%s' uses value encoding %d; only PLAIN and RLE_DICTIONARY are decoded", col.name.c_str(), pg.encoding);
-                        d.out = q.out_dev; d.out_off = pg.row_off;
-                        l_decode.push_back((int)tab.size());
-                    }
-                    if (comp) l_snappy.push_back((int)tab.size());
-                    tab.push_back(d);
-                }
-            }
-        }
-        // 3. device buffers
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        int rc = ensure_buf(ctx, &ctx->pq_stage, &ctx->pq_stage_bytes, stage_total + pq::kInWin + 256);
+        PqPlan P;
+        int rc = pq_plan(ctx, reqs, n_reqs, P);
         if (rc) return rc;
-        rc = ensure_buf(ctx, &ctx->pq_scratch, &ctx->pq_scratch_bytes, scratch_total + 256);
+        rc = pq_buffers(ctx, P);
         if (rc) return rc;
-        const size_t tab_bytes = align_up(tab.size() * sizeof(pq::PageDev), 256);
-        const size_t ls_bytes = align_up(l_snappy.size() * 4 + 4, 256), ld_bytes = align_up(l_decode.size() * 4 + 4, 256);
-        rc = ensure_buf(ctx, &ctx->pq_tab, &ctx->pq_tab_bytes, tab_bytes + ls_bytes + ld_bytes + 256);
-        if (rc) return rc;
-        char* tb = (char*)ctx->pq_tab;
-        pq::PageDev* d_tab = (pq::PageDev*)tb;
-        int* d_ls = (int*)(tb + tab_bytes); int* d_ld = (int*)(tb + tab_bytes + ls_bytes);
-        int* d_err = (int*)(tb + tab_bytes + ls_bytes + ld_bytes);
         hipStream_t st = ctx->stream;
-        for (const Span& s : merged)
+        for (const PqSpan& s : P.merged)
             HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->pq_stage + s.stage_off, s.f->bytes + s.start, (size_t)(s.end - s.start), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemsetAsync((char*)ctx->pq_stage + stage_total, 0, pq::kInWin + 256, st));
-        if (!tab.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(pq::PageDev), hipMemcpyHostToDevice, st));
-        if (!l_snappy.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ls, l_snappy.data(), l_snappy.size() * 4, hipMemcpyHostToDevice, st));
-        if (!l_decode.empty()) HIP_TRY(ctx, hipMemcpyAsync(d_ld, l_decode.data(), l_decode.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 8, st));
-        if (!l_snappy.empty())
-            LAUNCH(ctx, K_PQ_SNAPPY, pq::k_pq_snappy, dim3((unsigned)l_snappy.size()), dim3(64), 0, (const unsigned char*)ctx->pq_stage,
-                   (unsigned char*)ctx->pq_scratch, (const pq::PageDev*)d_tab, (const int*)d_ls, d_err);
-        if (!l_decode.empty())
-            LAUNCH(ctx, K_PQ_DECODE, pq::k_pq_decode, dim3((unsigned)l_decode.size()), dim3(256), 0, (const unsigned char*)ctx->pq_stage,
-                   (const unsigned char*)ctx->pq_scratch, (const pq::PageDev*)d_tab, (const int*)d_ld, d_err);
+        rc = pq_launch(ctx, P);
+        if (rc) return rc;
         int h_err[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(h_err, d_err, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(h_err, P.d_err, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         prof_resolve(ctx);
-        if (h_err[0]) {
-            static const char* const what[] = {"", "corrupt Snappy stream", "null values are not supported", "corrupt definition levels",
-                                               "corrupt RLE / bit-packed runs", "dictionary index out of range", "page shorter than its values"};
-            const int c = h_err[0];
-            return fail(ctx, MCR_EINVAL, "parquet: %s (page %d of the request)", (c > 0 && c < 7) ? what[c] : "decode error", h_err[1]);
-        }
+        rc = pq_error(ctx, h_err);
+        if (rc) return rc;
     } catch (const std::exception& e) {
         return fail(ctx, MCR_ENOMEM, "parquet: host allocation failed: %s", e.what());
     }
@@ -2147,6 +2226,8 @@ int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t 
 // ---- many files in one call -------------------------------------------------------------------------------
 
 struct mcr_fileset {
+    double phase_ms[MCR_FS_PHASES] = {0};
+    int n_q = 0;
     struct Entry {
         std::vector<std::string> names;
         i64 C = 0, N = 0;
@@ -2175,12 +2256,23 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
     if (min_chains < 1) return fail(ctx, MCR_EMINCHAINS_ARG, "min_chains must be >= 1; got %d", min_chains);
     if (n_q < 0 || n_q > MCR_MAX_QUANTILES || (n_q > 0 && !quantiles)) return fail(ctx, MCR_EINVAL, "bad quantile list");
     if (ctx->n_inflight) return fail(ctx, MCR_EINVAL, "mcr_summarize_files with summaries in flight");
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_start = clk::now();
+    double phase[MCR_FS_PHASES] = {0};
+    clk::time_point t_prev = t_start;
+    auto lap = [&](int k) { const clk::time_point now = clk::now(); phase[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
     try {
         std::vector<MappedFile> mf((size_t)n_paths);
         struct Plan { std::vector<int> cols; int chain = -1, draw = -1; i64 M = 0; size_t off = 0, ioff = 0; i64 C = 0, N = 0; };
         std::vector<Plan> plan((size_t)n_paths);
         size_t arena = 0, ids = 0;
-        // 1. map + parse
+        // 1. The files' images go WHOLE into one pinned host buffer (nearly every byte of a draws file is a column chunk this
+        //    call decodes): MCR_IO_THREADS host threads pread() them -- the page cache's copy lands in memory the DMA engine
+        //    reads directly; no mapping is set up or torn down (57 munmaps cost 2 ms of TLB shoot-downs in a process with
+        //    this many threads), no page faults, no pageable staging inside the runtime -- and parse each footer and its
+        //    page headers from that image, while THIS thread uploads the finished prefix behind them in pieces of >= 2 MB.
+        //    HIP calls stay on the calling thread.
+        std::vector<size_t> img_off((size_t)n_paths + 1, 0);
         for (int i = 0; i < n_paths; ++i) {
             MappedFile& m = mf[(size_t)i];
             m.fd = open(paths[i], O_RDONLY);
@@ -2188,11 +2280,68 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             if (m.fd < 0 || fstat(m.fd, &st) != 0) return fail(ctx, MCR_EINVAL, "cannot open %s", paths[i]);
             m.len = (size_t)st.st_size;
             if (m.len == 0) return fail(ctx, MCR_EINVAL, "parquet: %s is empty", paths[i]);
-            m.map = mmap(nullptr, m.len, PROT_READ, MAP_PRIVATE, m.fd, 0);
-            if (m.map == MAP_FAILED) return fail(ctx, MCR_EINVAL, "cannot map %s", paths[i]);
-            int rc = mcr_parquet_open(ctx, m.map, m.len, &m.pq);
-            if (rc) { char msg[400]; snprintf(msg, sizeof msg, "%s", ctx->err); return fail(ctx, rc, "%s: %s", paths[i], msg); }
-            const pq::File& f = m.pq->f;
+            img_off[(size_t)i + 1] = align_up(img_off[(size_t)i] + m.len, 256);
+        }
+        const size_t img_total = img_off[(size_t)n_paths];
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = ensure_buf(ctx, &ctx->pq_stage, &ctx->pq_stage_bytes, img_total + pq::kInWin + 256);
+        if (rc) return rc;
+        if (img_total > ctx->pq_pin_bytes) {                    // pinned staging, kept for the life of the context
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->pq_pin) { hipHostFree(ctx->pq_pin); ctx->pq_pin = nullptr; ctx->pq_pin_bytes = 0; }
+            const size_t want = img_total + (img_total >> 2);
+            HIP_TRY(ctx, hipHostMalloc(&ctx->pq_pin, want, hipHostMallocDefault));
+            ctx->pq_pin_bytes = want;
+        }
+        lap(MCR_FS_PH_OPEN);
+        std::vector<int> frc((size_t)n_paths, MCR_OK);
+        std::vector<std::string> ferr((size_t)n_paths);
+        if (n_paths > 0) {
+            char* pin = (char*)ctx->pq_pin;
+            std::vector<std::atomic<int>> done((size_t)n_paths);
+            for (auto& d : done) d.store(0, std::memory_order_relaxed);
+            std::atomic<int> next{0};
+            auto reader = [&]() {
+                for (int i; (i = next.fetch_add(1)) < n_paths;) {
+                    MappedFile& m = mf[(size_t)i];
+                    auto bad = [&](int code, const std::string& msg) { frc[(size_t)i] = code; ferr[(size_t)i] = msg; };
+                    try {
+                        size_t got = 0;
+                        while (got < m.len) {
+                            const ssize_t r = pread(m.fd, pin + img_off[(size_t)i] + got, m.len - got, (off_t)got);
+                            if (r <= 0) break;
+                            got += (size_t)r;
+                        }
+                        if (got < m.len) bad(MCR_EINVAL, std::string("short read of ") + paths[i]);
+                        else {
+                            m.pq = new mcr_parquet();
+                            if (!pq::open(m.pq->f, pin + img_off[(size_t)i], m.len)) bad(MCR_EINVAL, std::string(paths[i]) + ": parquet: " + m.pq->f.error);
+                        }
+                    } catch (const std::exception& e) { bad(MCR_ENOMEM, std::string("host allocation failed: ") + e.what()); }
+                    done[(size_t)i].store(1, std::memory_order_release);
+                }
+            };
+            std::vector<std::thread> th;
+            const int TR = std::max(1, std::min(ctx->io_threads, n_paths));
+            for (int t = 0; t < TR; ++t) th.emplace_back(reader);
+            int sent = 0;                                        // files [0, sent) are uploaded
+            hipError_t he = hipSuccess;
+            for (int i = 0; i < n_paths; ++i) {
+                while (done[(size_t)i].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                const size_t from = img_off[(size_t)sent], upto = img_off[(size_t)i + 1];
+                if (he == hipSuccess && (upto - from >= ctx->io_piece || i + 1 == n_paths)) {
+                    he = hipMemcpyAsync((char*)ctx->pq_stage + from, pin + from, upto - from, hipMemcpyHostToDevice, ctx->stream);
+                    sent = i + 1;
+                }
+            }
+            for (std::thread& x : th) x.join();
+            for (int i = 0; i < n_paths; ++i)
+                if (frc[(size_t)i]) { hipStreamSynchronize(ctx->stream); return fail(ctx, frc[(size_t)i], "%s", ferr[(size_t)i].c_str()); }
+            if (he != hipSuccess) return fail(ctx, MCR_EHIP, "hipMemcpyAsync of the file images failed: %s", hipGetErrorString(he));
+        }
+        lap(MCR_FS_PH_READ);
+        for (int i = 0; i < n_paths; ++i) {
+            const pq::File& f = mf[(size_t)i].pq->f;
             Plan& pl = plan[(size_t)i];
             for (int c = 0; c < (int)f.cols.size(); ++c) {
                 const int ty = f.cols[(size_t)c].type;
@@ -2201,15 +2350,15 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
                 else if (f.cols[(size_t)c].name == "draw") pl.draw = c;
                 else if (numeric) pl.cols.push_back(c);
             }
-            if (pl.chain < 0 || pl.draw < 0) return fail(ctx, MCR_EINVAL, "%s: no chain / draw columns", paths[i]);
+            if (pl.chain < 0 || pl.draw < 0) { hipStreamSynchronize(ctx->stream); return fail(ctx, MCR_EINVAL, "%s: no chain / draw columns", paths[i]); }
             pl.M = f.num_rows;
             pl.off = arena; arena += pl.cols.size() * (size_t)pl.M * 8;
             pl.ioff = ids; ids += (size_t)2 * (size_t)pl.M * 8;
         }
         // 2. one batched decode into the arena ([P][M] per file, packed) + chain / draw ids behind it
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
         const size_t ids_base = align_up(arena, 256);
-        int rc = ensure_buf(ctx, &ctx->fs_arena, &ctx->fs_arena_bytes, ids_base + ids + 256);
+        const size_t lay_base = align_up(ids_base + ids, 256), lay_out = align_up(lay_base + (size_t)n_paths * sizeof(pq::FileIds), 256);
+        rc = ensure_buf(ctx, &ctx->fs_arena, &ctx->fs_arena_bytes, lay_out + (size_t)n_paths * 32 + 256);
         if (rc) return rc;
         char* base = (char*)ctx->fs_arena;
         std::vector<mcr_parquet_request> reqs;
@@ -2220,40 +2369,56 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             reqs.push_back(mcr_parquet_request{mf[(size_t)i].pq, pl.chain, MCR_PQ_I64, base + ids_base + pl.ioff});
             reqs.push_back(mcr_parquet_request{mf[(size_t)i].pq, pl.draw, MCR_PQ_I64, base + ids_base + pl.ioff + (size_t)pl.M * 8});
         }
-        rc = mcr_parquet_decode(ctx, reqs.data(), (int)reqs.size());
-        if (rc) return rc;
-        std::vector<int64_t> h_ids(ids / 8);
-        if (ids) {
-            HIP_TRY(ctx, hipMemcpyAsync(h_ids.data(), base + ids_base, ids, hipMemcpyDeviceToHost, ctx->stream));
+        PqPlan PP;
+        if (!reqs.empty()) {
+            std::vector<FileBase> bases;
+            for (int i = 0; i < n_paths; ++i) bases.emplace_back(&mf[(size_t)i].pq->f, img_off[(size_t)i]);
+            std::sort(bases.begin(), bases.end(), [](const FileBase& a, const FileBase& b) { return std::less<const pq::File*>()(a.first, b.first); });
+            rc = pq_plan(ctx, reqs.data(), (int)reqs.size(), PP, &bases, img_total);
+            if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+            rc = pq_buffers(ctx, PP);            // (pq_stage is large enough already: no reallocation under the uploads in flight)
+            if (rc) return rc;
+        }
+        lap(MCR_FS_PH_PLAN);
+        // 2c. decode kernels + the chain / draw bookkeeping on the device (k_chain_layout: 32 bytes per file come back
+        //     instead of the id columns)
+        std::vector<i64> h_lay((size_t)n_paths * 4, 0);
+        int h_err[2] = {0, 0};
+        if (!reqs.empty()) {
+            rc = pq_launch(ctx, PP);
+            if (rc) return rc;
+            std::vector<pq::FileIds> fids((size_t)n_paths);
+            for (int i = 0; i < n_paths; ++i) {
+                const Plan& pl = plan[(size_t)i];
+                fids[(size_t)i] = pq::FileIds{(const i64*)(base + ids_base + pl.ioff), (const i64*)(base + ids_base + pl.ioff + (size_t)pl.M * 8), pl.M};
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(base + lay_base, fids.data(), fids.size() * sizeof(pq::FileIds), hipMemcpyHostToDevice, ctx->stream));
+            LAUNCH(ctx, K_GATHER, pq::k_chain_layout, dim3((unsigned)n_paths), dim3(256), 0, (const pq::FileIds*)(base + lay_base), (i64*)(base + lay_out));
+            HIP_TRY(ctx, hipMemcpyAsync(h_lay.data(), base + lay_out, (size_t)n_paths * 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(h_err, PP.d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            prof_resolve(ctx);
+            rc = pq_error(ctx, h_err);
+            if (rc) return rc;
         }
         // 3. chain / draw bookkeeping (convert._chains_from_table): rows must already be in (chain, draw) order
         for (int i = 0; i < n_paths; ++i) {
             Plan& pl = plan[(size_t)i];
-            const int64_t* ch = h_ids.data() + pl.ioff / 8;
-            const int64_t* dr = ch + pl.M;
-            i64 C = 0, first_len = -1, run = 0;
-            bool equal = true;
-            for (i64 r = 0; r < pl.M; ++r) {
-                const bool new_chain = r == 0 || ch[r] != ch[r - 1];
-                if (!new_chain && dr[r] < dr[r - 1]) return fail(ctx, MCR_ELAYOUT, "%s: rows are not in (chain, draw) order", paths[i]);
-                if (new_chain) {
-                    if (r > 0 && ch[r] < ch[r - 1]) return fail(ctx, MCR_ELAYOUT, "%s: rows are not in (chain, draw) order", paths[i]);
-                    if (r > 0) { if (first_len < 0) first_len = run; else if (run != first_len) equal = false; }
-                    ++C; run = 0;
-                }
-                ++run;
-            }
-            if (pl.M > 0) { if (first_len < 0) first_len = run; else if (run != first_len) equal = false; }
-            pl.C = C; pl.N = first_len < 0 ? 0 : first_len;
+            const i64* L = h_lay.data() + (size_t)i * 4;
+            if (pl.M > 0 && !L[3]) return fail(ctx, MCR_ELAYOUT, "%s: rows are not in (chain, draw) order", paths[i]);
+            const i64 C = pl.M > 0 ? L[0] : 0;
+            const bool equal = pl.M == 0 || L[2] != 0;
+            pl.C = C; pl.N = pl.M > 0 ? L[1] : 0;
             if (diagnostics && !pl.cols.empty()) {
                 if (C < min_chains) return fail(ctx, MCR_EMINCHAINS, "%s: R-hat diagnostics require at least %d chains; got %lld chain(s)", paths[i], min_chains, (long long)C);
                 if (!equal) return fail(ctx, MCR_ELAYOUT, "%s: chains of unequal length", paths[i]);
             }
             if (!diagnostics && !pl.cols.empty() && pl.M == 0) return fail(ctx, MCR_EINVAL, "%s: cannot compute stats of empty columns", paths[i]);
         }
+        lap(MCR_FS_PH_DECODE);
         // 4. result set + jobs (runs of neighbouring files of one shape are one tensor)
         std::unique_ptr<mcr_fileset> fs(new mcr_fileset());
+        fs->n_q = n_q;
         fs->files.resize((size_t)n_paths);
         for (int i = 0; i < n_paths; ++i) {
             mcr_fileset::Entry& e = fs->files[(size_t)i];
@@ -2309,6 +2474,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
         const int rw = wait_impl(ctx);
         if (err) { memcpy(ctx->err, keep, sizeof keep); return err; }
         if (rw) return rw;
+        lap(MCR_FS_PH_STATS);
         if (diagnostics)
             for (size_t k = 0; k < jobs.size(); ++k)
                 for (size_t p = 0; p < (size_t)jobs[k].P; ++p) {
@@ -2327,6 +2493,11 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
                 p0 += P;
             }
         }
+        lap(MCR_FS_PH_COLLECT);
+        mf.clear();                                   // unmap, close, free the parsed metadata
+        lap(MCR_FS_PH_CLOSE);
+        phase[MCR_FS_PH_TOTAL] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+        memcpy(fs->phase_ms, phase, sizeof phase);
         *out = fs.release();
         return MCR_OK;
     } catch (const std::exception& e) {
@@ -2351,6 +2522,43 @@ const double* mcr_fileset_field(const mcr_fileset* fs, int file, int field)
 {
     const auto* e = fs_entry(fs, file);
     return (e && field >= 0 && field < MCR_FS_FIELDS) ? e->f[field].data() : nullptr;
+}
+int64_t mcr_fileset_export(const mcr_fileset* fs, double* rows, int64_t cap_rows)
+{
+    if (!fs) return -1;
+    static const int order[10] = {MCR_FS_MEAN, MCR_FS_STD, MCR_FS_MEDIAN, MCR_FS_RHAT, MCR_FS_ESS_BULK, MCR_FS_ESS_TAIL,
+                                  MCR_FS_RHAT_BULK, MCR_FS_RHAT_TAIL, MCR_FS_LAG_BULK, MCR_FS_LAG_TAIL};
+    const size_t w = 10 + (size_t)fs->n_q;
+    int64_t row = 0;
+    for (const mcr_fileset::Entry& e : fs->files)
+        for (size_t p = 0; p < e.names.size(); ++p, ++row) {
+            if (!rows || row >= cap_rows) continue;
+            double* r = rows + (size_t)row * w;
+            for (int k = 0; k < 10; ++k) r[k] = e.f[order[k]][p];
+            for (int q = 0; q < fs->n_q; ++q) r[10 + q] = e.f[MCR_FS_Q][p * (size_t)fs->n_q + (size_t)q];
+        }
+    return row;
+}
+
+int64_t mcr_fileset_names(const mcr_fileset* fs, char* buf, int64_t cap)
+{
+    if (!fs) return -1;
+    int64_t need = 0;
+    for (const mcr_fileset::Entry& e : fs->files)
+        for (const std::string& n : e.names) {
+            const int64_t len = (int64_t)n.size() + 1;
+            if (buf && need + len <= cap) memcpy(buf + need, n.c_str(), (size_t)len);
+            need += len;
+        }
+    return need;
+}
+
+int mcr_fileset_phases(const mcr_fileset* fs, double* ms, int cap)
+{
+    if (!fs || !ms || cap < 0) return -1;
+    const int n = cap < MCR_FS_PHASES ? cap : MCR_FS_PHASES;
+    for (int k = 0; k < n; ++k) ms[k] = fs->phase_ms[k];
+    return MCR_FS_PHASES;
 }
 void mcr_fileset_free(mcr_fileset* fs) { delete fs; }
 

@@ -631,5 +631,47 @@ __global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ 
     if (k < M) dst[p * M + k] = src[p * M + order[k]];
 }
 
+// The integer bookkeeping of `_chains_from_table` (src/mcmc_ref/convert.py:150-161) for files whose rows are already in
+// (chain, draw) order, on the device: one workgroup per file walks its decoded chain / draw id columns and leaves
+//   out[4 f + 0] = number of chains (maximal runs of equal chain id), [1] = length of the first run,
+//   [2] = 1 if every run has that length, [3] = 1 if the rows are in (chain id ascending, draw ascending) order
+// so that only 32 bytes per file come back to the host instead of the id columns (9 MB for the packaged corpus).
+// Runs are all `L` long iff every run boundary sits at a multiple of L and there are M / L runs.
+struct FileIds { const i64* chain; const i64* draw; i64 M; };
+__global__ __launch_bounds__(256) void k_chain_layout(const FileIds* __restrict__ files, i64* __restrict__ out)
+{
+    __shared__ unsigned long long s_first;
+    __shared__ unsigned s_bounds, s_bad, s_uneven;
+    const FileIds f = files[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_first = (unsigned long long)f.M; s_bounds = 0u; s_bad = 0u; s_uneven = 0u; }
+    __syncthreads();
+    unsigned nb = 0, bad = 0;
+    unsigned long long first = (unsigned long long)f.M;
+    for (i64 r = 1 + tid; r < f.M; r += 256) {
+        const i64 c0 = f.chain[r - 1], c1 = f.chain[r];
+        if (c1 != c0) { ++nb; if (c1 < c0) bad = 1u; if ((unsigned long long)r < first) first = (unsigned long long)r; }
+        else if (f.draw[r] < f.draw[r - 1]) bad = 1u;
+    }
+    if (nb) { atomicAdd(&s_bounds, nb); atomicMin(&s_first, first); }
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    const i64 L = (i64)s_first;          // length of the first run (M when there is one chain)
+    unsigned uneven = 0;
+    if (L > 0)
+        for (i64 r = 1 + tid; r < f.M; r += 256)
+            if (f.chain[r] != f.chain[r - 1] && r % L != 0) uneven = 1u;
+    if (uneven) atomicOr(&s_uneven, 1u);
+    __syncthreads();
+    if (tid == 0) {
+        const i64 Cn = f.M > 0 ? (i64)s_bounds + 1 : 0;
+        const bool equal = f.M == 0 || (!s_uneven && L > 0 && f.M % L == 0 && Cn == f.M / L);
+        out[4 * blockIdx.x + 0] = Cn;
+        out[4 * blockIdx.x + 1] = f.M > 0 ? L : 0;
+        out[4 * blockIdx.x + 2] = equal ? 1 : 0;
+        out[4 * blockIdx.x + 3] = s_bad ? 0 : 1;
+    }
+}
+
 }  // namespace pq
 }  // namespace mcr

@@ -278,7 +278,12 @@ def _entry(r: dict, i: int, qs, diagnostics: bool) -> dict[str, float]:
 _FS_FIELDS = (("mean", 0), ("std", 1), ("rhat", 4), ("ess_bulk", 5), ("ess_tail", 6))
 
 
-def _summarize_paths(ctx: "_ffi.Context", paths: list[str], min_chains: int, qs: list[float], diagnostics: bool):
+FS_PHASES = ("open_ms", "read_pinned_parse_ms", "plan_ms", "upload_decode_layout_ms", "statistics_ms",
+             "collect_ms", "close_ms", "total_ms")          # MCR_FS_PH_* of include/mcmcref_hip.h
+
+
+def _summarize_paths(ctx: "_ffi.Context", paths: list[str], min_chains: int, qs: list[float], diagnostics: bool,
+                     phases: dict | None = None):
     """All of summarize_files in ONE C call (mcr_summarize_files: mmap, parse, batched decode, layout check,
     pipelined statistics).  Returns None when a file needs the general route (rows out of (chain, draw) order,
     chains of unequal length)."""
@@ -298,23 +303,33 @@ def _summarize_paths(ctx: "_ffi.Context", paths: list[str], min_chains: int, qs:
             raise ValueError("cannot compute stats of empty columns")
         raise McrError(rc, msg)
     try:
-        out = []
+        if phases is not None:
+            ms = (C.c_double * len(FS_PHASES))()
+            L.mcr_fileset_phases(fs, ms, len(FS_PHASES))
+            phases.update(zip(FS_PHASES, (float(v) for v in ms)))
         nq = len(qs)
         qkeys = [f"q{int(v * 100)}" for v in qs]
-        for i in range(L.mcr_fileset_size(fs)):
-            P = int(L.mcr_fileset_params(fs, i))
-            names = [L.mcr_fileset_param_name(fs, i, j).decode() for j in range(P)]
-            cols = {k: np.ctypeslib.as_array(L.mcr_fileset_field(fs, i, f), shape=(P,)).tolist() if P else []
-                    for k, f in _FS_FIELDS if diagnostics or f < 2}
-            qq = np.ctypeslib.as_array(L.mcr_fileset_field(fs, i, 2), shape=(P, nq)).tolist() if P and nq else [[]] * P
+        nfiles = L.mcr_fileset_size(fs)
+        counts = [int(L.mcr_fileset_params(fs, i)) for i in range(nfiles)]
+        total = sum(counts)
+        rows = np.empty((max(total, 1), 10 + nq))                  # one export of the whole set (mcr_fileset_export)
+        L.mcr_fileset_export(fs, rows.ctypes.data_as(C.POINTER(C.c_double)), total)
+        need = int(L.mcr_fileset_names(fs, None, 0))
+        buf = C.create_string_buffer(max(need, 1))
+        L.mcr_fileset_names(fs, buf, need)
+        names = buf.raw[:need].decode().split("\0")[:total]
+        table = rows[:total].tolist()
+        out, r = [], 0
+        for P in counts:
             res = {}
-            for j, name in enumerate(names):
-                e = {"mean": cols["mean"][j], "std": cols["std"][j]}
-                e.update(zip(qkeys, qq[j]))
+            for name, row in zip(names[r:r + P], table[r:r + P]):
+                e = {"mean": row[0], "std": row[1]}
+                e.update(zip(qkeys, row[10:]))
                 if diagnostics:
-                    e.update(rhat=cols["rhat"][j], ess_bulk=cols["ess_bulk"][j], ess_tail=cols["ess_tail"][j])
+                    e["rhat"], e["ess_bulk"], e["ess_tail"] = row[3], row[4], row[5]
                 res[name] = e
             out.append(res)
+            r += P
         return out
     finally:
         L.mcr_fileset_free(fs)

@@ -80,6 +80,12 @@ def main():
         def native_pass():
             return parquet.summarize_files(ctx, paths)
 
+        def native_phases():
+            """Per-phase host clock of ONE mcr_summarize_files call (mcr_fileset_phases)."""
+            ph = {}
+            parquet._summarize_paths(ctx, [str(p) for p in paths], 4, [0.05, 0.5, 0.95], True, ph)
+            return ph
+
         ra, _, _ = arrow_pass()
         rn = native_pass()
         same = ra == rn
@@ -89,6 +95,8 @@ def main():
         tn = []
         for _ in range(reps):
             t0 = time.perf_counter(); native_pass(); tn.append(time.perf_counter() - t0)
+        phase_runs = [native_phases() for _ in range(reps)]
+        phases = {k: sorted(r[k] for r in phase_runs)[len(phase_runs) // 2] for k in phase_runs[0]}      # medians
         # decode alone (metadata parse + upload + kernels), and the kernels by HIP events
         files = [parquet.ParquetFile(p, ctx) for p in paths]
         t0 = time.perf_counter()
@@ -113,6 +121,7 @@ def main():
         "identical_statistics": bool(same),
         "arrow_route_s": best_a[0], "arrow_decode_s": best_a[1], "arrow_upload_summarise_s": best_a[2],
         "native_route_s": min(tn),
+        "native_phases_ms_median": {k: round(v, 3) for k, v in phases.items()},
         "native_decode_only_s": t_decode,
         "speedup_end_to_end": best_a[0] / min(tn),
         "param_draws_per_s_native": total_pd / min(tn), "param_draws_per_s_arrow": total_pd / best_a[0],
