@@ -827,4 +827,17 @@ def traffic_table() -> dict:
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    try:
+        sys.exit(main())
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001
+        # A rank that fails -- a collective past its deadline (MCR_COMM_TIMEOUT_S: a peer died or never came), a bad file --
+        # reports and LEAVES: with several ranks a normal interpreter exit can wait for ever inside librccl's teardown
+        # when a peer is gone, and the launcher only ends the job when every rank has ended.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush(); sys.stdout.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MCR_BENCH_FORCE_DIST") == "1":
+            os._exit(3)
+        sys.exit(1)

@@ -1824,6 +1824,9 @@ struct mcr_comm {
     hipStream_t stream = nullptr;
     int world = 1, rank = 0;
     void* dbuf = nullptr; size_t dbytes = 0;      // device staging (send block + receive blocks)
+    bool nonblocking = false;                     // communicator created with config.blocking = 0: every wait has a deadline
+    bool dead = false;                            // aborted after a deadline or an asynchronous error
+    double timeout_s = 300.0;                     // MCR_COMM_TIMEOUT_S
 };
 
 namespace {
@@ -1839,6 +1842,82 @@ int comm_buf(mcr_comm* c, size_t bytes)
     HIP_TRY(c->ctx, hipMalloc(&c->dbuf, bytes));
     c->dbytes = bytes;
     return MCR_OK;
+}
+
+// A DEADLINE ON EVERY COLLECTIVE.  The ranks are separate processes; one that dies after the
+// rendezvous (the reference's generate loop carries on past a failed recipe, src/mcmc_ref/generate.py:77-96 -- a sharded
+// one must at least not hang on it) would leave its peers inside ncclCommInitRank / ncclAllGather for ever.  The
+// communicator is therefore created NON-BLOCKING (ncclCommInitRankConfig, config.blocking = 0): every RCCL call returns
+// at once, and comm_wait polls ncclCommGetAsyncError / hipStreamQuery against MCR_COMM_TIMEOUT_S (default 300 s; the
+// first ncclCommInitRank of a node can take tens of seconds).  On expiry, or on an asynchronous RCCL error, the
+// communicator is aborted (ncclCommAbort: its kernels and its bootstrap sockets are torn down, nothing stays blocked),
+// marked dead, and the call returns MCR_ECOMM naming the call, the rank and the time; every later call on it fails at once.
+using comm_clock = std::chrono::steady_clock;
+
+// ncclCommAbort with a bound of its own: measured on RCCL 2.27.7, aborting a communicator whose ncclCommInitRank is still
+// waiting for a peer does not return (it joins the bootstrap it is meant to cancel).  The abort therefore runs on a helper
+// thread that this call waits for at most kAbortGraceS; a helper that has not come back by then is left behind (detached:
+// it owns nothing but the communicator handle, which nobody uses again) -- the caller gets its error either way.
+constexpr double kAbortGraceS = 5.0;
+void bounded_abort(ncclComm_t nccl)
+{
+    mcr::comm::Api* a = mcr::comm::api();
+    if (!a || !a->CommAbort || !nccl) return;
+    auto done = std::make_shared<std::atomic<int>>(0);
+    std::thread([a, nccl, done]() { a->CommAbort(nccl); done->store(1, std::memory_order_release); }).detach();
+    const comm_clock::time_point t0 = comm_clock::now();
+    while (!done->load(std::memory_order_acquire) && std::chrono::duration<double>(comm_clock::now() - t0).count() < kAbortGraceS)
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+}
+
+int comm_abort(mcr_comm* c, const char* what, const char* why)
+{
+    bounded_abort(c->nccl);
+    c->nccl = nullptr;
+    c->dead = true;
+    return fail(c->ctx, MCR_ECOMM, "%s: rank %d of %d gave up: %s (MCR_COMM_TIMEOUT_S = %g s); the communicator was aborted",
+                what, c->rank, c->world, why, c->timeout_s);
+}
+
+// Waits until the communicator's pending RCCL call has been issued (non-blocking mode: state leaves ncclInProgress) and,
+// with `stream`, until the work on its stream has finished.
+int comm_wait(mcr_comm* c, const char* what, bool stream)
+{
+    mcr::comm::Api* a = mcr::comm::api();
+    const comm_clock::time_point t0 = comm_clock::now();
+    auto expired = [&]() { return std::chrono::duration<double>(comm_clock::now() - t0).count() > c->timeout_s; };
+    auto nap = [&](int& spins) { if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); };
+    int spins = 0;
+    if (c->nonblocking) {
+        for (;;) {
+            ncclResult_t st = ncclSuccess;
+            const ncclResult_t r = a->CommGetAsyncError(c->nccl, &st);
+            if (r != ncclSuccess) { comm_abort(c, what, "ncclCommGetAsyncError failed"); return MCR_ECOMM; }
+            if (st == ncclSuccess) break;
+            if (st != ncclInProgress) {
+                char why[160];
+                snprintf(why, sizeof why, "asynchronous RCCL error: %s", a->GetErrorString ? a->GetErrorString(st) : "?");
+                return comm_abort(c, what, why);
+            }
+            if (expired()) return comm_abort(c, what, "a peer did not arrive before the deadline");
+            nap(spins);
+        }
+    }
+    if (!stream) return MCR_OK;
+    if (!c->nonblocking) { HIP_TRY(c->ctx, hipStreamSynchronize(c->stream)); return MCR_OK; }
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return MCR_OK;
+        if (q != hipErrorNotReady) return fail(c->ctx, MCR_EHIP, "%s: hipStreamQuery failed: %s", what, hipGetErrorString(q));
+        ncclResult_t st = ncclSuccess;
+        if (a->CommGetAsyncError(c->nccl, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) {
+            char why[160];
+            snprintf(why, sizeof why, "asynchronous RCCL error: %s", a->GetErrorString ? a->GetErrorString(st) : "?");
+            return comm_abort(c, what, why);
+        }
+        if (expired()) return comm_abort(c, what, "the collective did not complete before the deadline (a peer is gone or stuck)");
+        nap(spins);
+    }
 }
 }  // namespace
 
@@ -1866,12 +1945,63 @@ int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** 
     mcr_comm* c = new (std::nothrow) mcr_comm();
     if (!c) return fail(ctx, MCR_ENOMEM, "out of host memory");
     c->ctx = ctx; c->world = world; c->rank = rank;
+    if (const char* env = getenv("MCR_COMM_TIMEOUT_S")) { const double v = atof(env); if (v > 0.0) c->timeout_s = v; }
+    const char* blk = getenv("MCR_COMM_BLOCKING");
+    c->nonblocking = a->nonblocking() && !(blk && atoi(blk) != 0);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(ctx, MCR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    const ncclResult_t r = a->CommInitRank(&c->nccl, world, uid, rank);      // collective: every rank of the world calls it
-    if (r != ncclSuccess) { hipStreamDestroy(c->stream); delete c; return comm_fail(ctx, "ncclCommInitRank", r); }
+    // collective: every rank of the world calls it
+    if (c->nonblocking) {
+        // The whole init runs on a helper thread and THIS thread only watches the clock: on RCCL 2.27.7 neither the init of a
+        // rank whose peers never come nor an abort of it is guaranteed to return, and the caller must get its error anyway.
+        struct InitJob {
+            std::atomic<int> state{0}, cancel{0};      // state 1: finished (r / async say how)
+            std::atomic<ncclComm_t> nccl{nullptr};
+            ncclResult_t r = ncclSuccess, async = ncclSuccess;
+        };
+        auto job = std::make_shared<InitJob>();
+        const int dev = ctx->device;
+        std::thread([a, job, dev, world, uid, rank]() {
+            hipSetDevice(dev);
+            ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+            cfg.blocking = 0;
+            ncclComm_t h = nullptr;
+            job->r = a->CommInitRankConfig(&h, world, uid, rank, &cfg);
+            job->nccl.store(h, std::memory_order_release);
+            if ((job->r == ncclSuccess || job->r == ncclInProgress) && h) {
+                ncclResult_t st = ncclInProgress;
+                int spins = 0;
+                while (!job->cancel.load(std::memory_order_acquire)) {
+                    if (a->CommGetAsyncError(h, &st) != ncclSuccess) { st = ncclInternalError; break; }
+                    if (st != ncclInProgress) break;
+                    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                job->async = st;
+            }
+            job->state.store(1, std::memory_order_release);
+        }).detach();
+        const comm_clock::time_point t0 = comm_clock::now();
+        int spins = 0;
+        while (!job->state.load(std::memory_order_acquire) &&
+               std::chrono::duration<double>(comm_clock::now() - t0).count() <= c->timeout_s)
+            if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        int rc = MCR_OK;
+        if (!job->state.load(std::memory_order_acquire)) {
+            job->cancel.store(1, std::memory_order_release);
+            bounded_abort(job->nccl.load(std::memory_order_acquire));
+            rc = fail(ctx, MCR_ECOMM, "ncclCommInitRank: rank %d of %d gave up: a peer did not arrive before the deadline "
+                      "(MCR_COMM_TIMEOUT_S = %g s); the communicator was aborted", rank, world, c->timeout_s);
+        } else if (job->r != ncclSuccess && job->r != ncclInProgress) rc = comm_fail(ctx, "ncclCommInitRankConfig", job->r);
+        else if (!job->nccl.load()) rc = fail(ctx, MCR_ECOMM, "ncclCommInitRankConfig returned no communicator");
+        else if (job->async != ncclSuccess) { bounded_abort(job->nccl.load()); rc = comm_fail(ctx, "ncclCommInitRank (asynchronous)", job->async); }
+        if (rc) { hipStreamDestroy(c->stream); delete c; return rc; }
+        c->nccl = job->nccl.load();
+    } else {
+        const ncclResult_t r = a->CommInitRank(&c->nccl, world, uid, rank);
+        if (r != ncclSuccess) { hipStreamDestroy(c->stream); delete c; return comm_fail(ctx, "ncclCommInitRank", r); }
+    }
     *out = c;
     return MCR_OK;
 }
@@ -1880,9 +2010,17 @@ void mcr_comm_free(mcr_comm* c)
 {
     if (!c) return;
     hipSetDevice(c->ctx->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
     mcr::comm::Api* a = mcr::comm::api();
-    if (a && c->nccl) a->CommDestroy(c->nccl);
+    if (c->nccl && !c->dead) {
+        if (c->nonblocking) {
+            if (comm_wait(c, "mcr_comm_free", true) == MCR_OK && c->nccl) {
+                a->CommDestroy(c->nccl);            // (returns ncclInProgress on a non-blocking communicator: finalisation goes on inside RCCL)
+            }
+        } else {
+            if (c->stream) hipStreamSynchronize(c->stream);
+            if (a) a->CommDestroy(c->nccl);
+        }
+    }
     if (c->dbuf) hipFree(c->dbuf);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1890,6 +2028,7 @@ void mcr_comm_free(mcr_comm* c)
 
 int mcr_comm_world(const mcr_comm* c) { return c ? c->world : -1; }
 int mcr_comm_rank(const mcr_comm* c) { return c ? c->rank : -1; }
+int mcr_comm_has_deadline(const mcr_comm* c) { return (c && c->nonblocking) ? 1 : 0; }
 
 // THE collective of the path: every rank contributes `count` doubles, every rank receives world * count doubles in
 // rank order (ncclAllGather over xGMI).  Host pointers; staged through a small device buffer on the communicator's stream.
@@ -1897,6 +2036,7 @@ int mcr_comm_all_gather(mcr_comm* c, const double* send, int64_t count, double* 
 {
     if (!c) return fail(nullptr, MCR_EINVAL, "comm is NULL");
     mcr_ctx* ctx = c->ctx;
+    if (c->dead) return fail(ctx, MCR_ECOMM, "ncclAllGather: the communicator of rank %d was aborted by an earlier failure", c->rank);
     if (count < 0 || (count > 0 && (!send || !recv))) return fail(ctx, MCR_EINVAL, "bad argument");
     if (count == 0) return MCR_OK;
     mcr::comm::Api* a = mcr::comm::api();
@@ -1908,10 +2048,11 @@ int mcr_comm_all_gather(mcr_comm* c, const double* send, int64_t count, double* 
     char* d_recv = d_send + align_up(sb, 256);
     HIP_TRY(ctx, hipMemcpyAsync(d_send, send, sb, hipMemcpyHostToDevice, c->stream));
     const ncclResult_t r = a->AllGather(d_send, d_recv, (size_t)count, ncclDouble, c->nccl, c->stream);
-    if (r != ncclSuccess) return comm_fail(ctx, "ncclAllGather", r);
+    if (r != ncclSuccess && r != ncclInProgress) return comm_fail(ctx, "ncclAllGather", r);
+    rc = comm_wait(c, "ncclAllGather", false);                 // issued (non-blocking mode)
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(recv, d_recv, rb, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(c->stream));
-    return MCR_OK;
+    return comm_wait(c, "ncclAllGather", true);
 }
 
 // Element-wise reduction of n host doubles over the ranks, in place (op: 0 sum, 1 max, 2 min): the bench's
@@ -1920,6 +2061,7 @@ int mcr_comm_all_reduce(mcr_comm* c, double* vals, int64_t n, int op)
 {
     if (!c) return fail(nullptr, MCR_EINVAL, "comm is NULL");
     mcr_ctx* ctx = c->ctx;
+    if (c->dead) return fail(ctx, MCR_ECOMM, "ncclAllReduce: the communicator of rank %d was aborted by an earlier failure", c->rank);
     if (n < 0 || (n > 0 && !vals) || op < 0 || op > 2) return fail(ctx, MCR_EINVAL, "bad argument");
     if (n == 0) return MCR_OK;
     mcr::comm::Api* a = mcr::comm::api();
@@ -1930,10 +2072,11 @@ int mcr_comm_all_reduce(mcr_comm* c, double* vals, int64_t n, int op)
     HIP_TRY(ctx, hipMemcpyAsync(c->dbuf, vals, b, hipMemcpyHostToDevice, c->stream));
     const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
     const ncclResult_t r = a->AllReduce(c->dbuf, c->dbuf, (size_t)n, ncclDouble, ops[op], c->nccl, c->stream);
-    if (r != ncclSuccess) return comm_fail(ctx, "ncclAllReduce", r);
+    if (r != ncclSuccess && r != ncclInProgress) return comm_fail(ctx, "ncclAllReduce", r);
+    rc = comm_wait(c, "ncclAllReduce", false);
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(vals, c->dbuf, b, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(c->stream));
-    return MCR_OK;
+    return comm_wait(c, "ncclAllReduce", true);
 }
 
 int mcr_comm_barrier(mcr_comm* c)

@@ -31,6 +31,12 @@ struct Api {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // the non-blocking mode (a deadline on every collective: mcr_api.hip, comm_wait): optional -- a librccl without
+    // them runs the blocking calls as before
+    decltype(&ncclCommInitRankConfig) CommInitRankConfig = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    bool nonblocking() const { return CommInitRankConfig && CommGetAsyncError && CommAbort; }
 };
 
 // Resolved once per process.  Returns nullptr (api_why() says why) when RCCL cannot be loaded.
@@ -61,6 +67,9 @@ inline Api* api()
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(a.handle); a.handle = nullptr; return nullptr; }
+    a.CommInitRankConfig = reinterpret_cast<decltype(a.CommInitRankConfig)>(dlsym(a.handle, "ncclCommInitRankConfig"));
+    a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(dlsym(a.handle, "ncclCommGetAsyncError"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.handle, "ncclCommAbort"));
     return &a;
 }
 

@@ -104,6 +104,7 @@ SYMBOLS = {
     "mcr_comm_free": (None, [C.c_void_p]),
     "mcr_comm_world": (C.c_int, [C.c_void_p]),
     "mcr_comm_rank": (C.c_int, [C.c_void_p]),
+    "mcr_comm_has_deadline": (C.c_int, [C.c_void_p]),
     "mcr_comm_all_gather": (C.c_int, [C.c_void_p, _dp, _I64, _dp]),
     "mcr_comm_all_reduce": (C.c_int, [C.c_void_p, _dp, _I64, C.c_int]),
     "mcr_comm_barrier": (C.c_int, [C.c_void_p]),

@@ -201,6 +201,12 @@ class Communicator:
         ctx._check(L.mcr_comm_init(ctx.handle, uid, self.world, self.rank, C.byref(h)))   # collective
         self.handle = h
 
+    @property
+    def has_deadline(self) -> bool:
+        """True: the RCCL communicator is non-blocking and every collective gives up after MCR_COMM_TIMEOUT_S (default
+        300 s) with an McrError(MCR_ECOMM) instead of waiting for a dead peer for ever (mcr_comm_has_deadline)."""
+        return bool(self.ctx.lib.mcr_comm_has_deadline(self.handle))
+
     def all_gather(self, arr: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(arr, dtype=np.float64)
         out = np.empty((self.world,) + a.shape, dtype=np.float64)

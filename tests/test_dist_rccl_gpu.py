@@ -47,6 +47,7 @@ def test_communicator_collectives_one_rank(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     with _ffi.Context(0) as ctx, shard.Communicator(ctx, world=1, rank=0) as comm:
         assert (comm.world, comm.rank) == (1, 0)
+        assert comm.has_deadline                                    # non-blocking communicator: every wait below is bounded
         assert list(tmp_path.iterdir()) == []                       # rank 0 removed the id file after the init
         x = np.arange(48.0).reshape(3, 16)
         assert np.array_equal(comm.all_gather(x), x[None])
@@ -64,3 +65,40 @@ def test_communicator_collectives_one_rank(tmp_path, monkeypatch):
         whole = ctx.summarize(x3, "pcn")
         assert np.array_equal(split[:, shard.RECORD_FIELDS.index("ess_bulk")], whole["ess_bulk"])
         assert split[:, shard.RECORD_FIELDS.index("param_idx")].tolist() == list(range(6))
+
+
+_ABSENT_PEER = r"""
+import ctypes as C, sys, time
+sys.path[:0] = [{root!r}, {pkg!r}]
+from mcmc_ref_hip import _ffi
+L = _ffi.load_library()
+ctx = _ffi.Context(0)
+uid = C.create_string_buffer(_ffi.MCR_COMM_ID_BYTES if hasattr(_ffi, "MCR_COMM_ID_BYTES") else 128)
+assert L.mcr_comm_unique_id(uid, len(uid)) == 0
+h = C.c_void_p()
+t0 = time.time()
+rc = L.mcr_comm_init(ctx.handle, uid, 2, 0, C.byref(h))            # a world of two, and rank 1 never comes
+dt = time.time() - t0
+print("RC", rc, "SECONDS", round(dt, 1), "MSG", (L.mcr_last_error(ctx.handle) or b"").decode(), flush=True)
+ok = ctx.summarize(__import__("numpy").random.default_rng(0).normal(size=(2, 4, 200)), "pcn")    # the context still works
+print("STILL_WORKS", bool(ok["ess_bulk"][0] > 0), flush=True)
+import os
+os._exit(0)     # RCCL 2.27.7 does not return from aborting an init that waits for a peer: the helper thread that tried is
+                # still inside it, and a normal interpreter exit would wait for librccl's teardown (bench.py leaves the same way)
+"""
+
+
+def test_a_peer_that_never_arrives_ends_in_an_error_not_a_hang(tmp_path):
+    """ncclCommInitRank with a world of two and only this rank present.  The non-blocking communicator
+    gives up after MCR_COMM_TIMEOUT_S, aborts itself and returns MCR_ECOMM naming the call and the rank; the process goes
+    on (its context still computes).  Runs in a child with a hard limit so that a hang would fail, not stall, the suite."""
+    from mcmc_ref_hip import _ffi
+    env = dict(os.environ, MCR_COMM_TIMEOUT_S="4")
+    code = _ABSENT_PEER.format(root=str(ROOT), pkg=str(ROOT / "mcmc-db_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=75, cwd=str(ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RC ")][0].split()
+    assert int(line[1]) == _ffi.MCR_ECOMM, r.stdout
+    assert 3.0 <= float(line[3]) <= 60.0, r.stdout
+    assert "rank 0 of 2 gave up" in r.stdout and "ncclCommInitRank" in r.stdout and "did not arrive" in r.stdout
+    assert "STILL_WORKS True" in r.stdout

@@ -111,3 +111,27 @@ def test_exchange_edge_cases(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="MCR_COMM_DIR"):
         shard.exchange_unique_id(1, 4, lambda: bytes(128), timeout=30)
     assert time.monotonic() - t0 < 1.0
+
+
+def test_a_rank_that_dies_after_the_rendezvous(tmp_path):
+    """VERDICT r3 item 5, the control flow on CPU: two ranks over the gloo stand-in, rank 1 dies (os._exit) right after
+    the barrier that ends the rendezvous; rank 0's failure agreement / record gather (mcmc_ref_hip.shard) must raise
+    within the collective's deadline and the process must leave with a non-zero code -- nobody waits for ever.  (The
+    product's own deadline lives in the library: MCR_COMM_TIMEOUT_S on the non-blocking RCCL communicator, exercised on
+    the GPU box by tests/test_dist_rccl_gpu.py::test_a_peer_that_never_arrives_ends_in_an_error_not_a_hang.)"""
+    import socket
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = str(ROOT / "tests" / "dead_peer_worker.py")
+    deadline = 20.0
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(deadline)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    took = time.time() - t0
+    assert procs[1].returncode == 17                                   # the rank that died
+    assert procs[0].returncode == 3, (outs[0][0][-800:], outs[0][1][-800:])
+    assert "RAISED" in outs[0][0] and "NO ERROR" not in outs[0][0]
+    assert took < 60 + deadline
