@@ -122,6 +122,7 @@ struct mcr_ctx {
     // between each of the ~12 kernels).  Disabled while profiling (events sit between kernels).
     bool fft_on = true;      // MCR_FFT=0: long chains take the direct tier-3 rounds only (A/B measurements, parity tests)
     bool f32_records = true; // MCR_F32_RECORDS=0: f32 tensors take the f64 kernels (widened by the tile sort) instead of mcr_sort32.hpp
+    bool splitters_pairwise = false;   // MCR_SPLITTERS_PAIRWISE=1: rank the regular samples pair by pair whatever their number (A/B, parity tests)
     int sort_cfg = 10;       // MCR_SORT_CFG = tile + 10 * merge geometry (see sort_stage_i); default: tile 256 x 16, merges 512 x 8
     size_t dbg_lds_pad[3] = {0, 0, 0};   // MCR_DBG_LDS_PAD="t,b,f": extra dynamic LDS bytes for tile sort / bucket merge / fold (occupancy experiments)
     double rho_band = kRhoBand;   // MCR_RHO_BAND: half-width of the guard band of the tier-3 scan (0 = decide on the raw values)
@@ -507,6 +508,31 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     return MCR_OK;
 }
 
+// k_splitters for the runs in `keys`: few samples (S <= 1024) are ranked pair by pair, more by merging the runs' sample
+// lists in the LDS (MVT outputs per thread and round: the smallest of 2, 4, 8 that holds S samples in 1024 MVT slots).
+template <typename KT, int MVT>
+int launch_splitters_v(mcr_ctx* ctx, const PipeIn& a, const KT* keys)
+{
+    const int S = a.bk_k * (int)(a.bk_R / 64);
+    const size_t lds_spl = splitters_lds_bytes(S, a.bk_B, a.bk_k, MVT);
+    if (lds_spl > 160 * 1024) return fail(ctx, MCR_ENOMEM, "k_splitters needs %zu bytes of LDS", lds_spl);
+    if (lds_spl > 60 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters<KT, MVT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
+    LAUNCH(ctx, K_SPLITTERS, (k_splitters<KT, MVT>), dim3((unsigned)a.pc), dim3(1024), lds_spl, keys, (const double*)a.samp,
+           a.M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
+    return MCR_OK;
+}
+template <typename KT>
+int launch_splitters(mcr_ctx* ctx, const PipeIn& a, const KT* keys)
+{
+    const int S = a.bk_k * (int)(a.bk_R / 64);
+    if (S <= 1024 || ctx->splitters_pairwise) return launch_splitters_v<KT, 0>(ctx, a, keys);
+    if (S <= 2048) return launch_splitters_v<KT, 2>(ctx, a, keys);
+    if (S <= 4096) return launch_splitters_v<KT, 4>(ctx, a, keys);
+    return launch_splitters_v<KT, 8>(ctx, a, keys);       // (MVT must divide the runs' 64 j samples: a thread's outputs never straddle two pairs of runs)
+}
+
 // Tile sort + (bucket partition | merge passes): leaves the pooled ascending (key, idx) order of every
 // parameter in *kin / *iin (one of the two ping-pong sets) and, on the bucket path with do_diag, z_bulk.
 // (TNT, TVT): threads x draws per lane of the tile sort; (MNT, MVT): of the merge kernels (bucket merge, fold, passes).
@@ -546,13 +572,10 @@ int sort_stage_t(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double**
         if (a.bk_R != kTile)
             LAUNCH(ctx, K_SPLITTERS, k_sample_runs<double>, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const double*)kin, M,
                    a.bk_R, a.samp);
-        const int S = a.bk_k * (int)(a.bk_R / 64);
-        const size_t lds_spl = (size_t)S * 12 + (size_t)(a.bk_B + 1) * 16 + (size_t)(a.bk_B + 1) * a.bk_k * 4 + 64;
-        if (lds_spl > 60 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters<double>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
-        LAUNCH(ctx, K_SPLITTERS, k_splitters<double>, dim3(py), dim3(1024), lds_spl, (const double*)kin, (const double*)a.samp,
-               M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
+        {
+            const int rc = launch_splitters<double>(ctx, a, (const double*)kin);
+            if (rc) return rc;
+        }
         const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);   // XCD-aware 1-D grid (xcd_map)
         LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge<MNT, MVT, IdxT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), lds_tile + ctx->dbg_lds_pad[1],
                (const double*)kin, (const IdxT*)iin, kout, iout, M, a.bk_k, a.bk_B, (const u32*)a.cut,
@@ -606,13 +629,10 @@ int sort_stage_rec(mcr_ctx* ctx, PipeIn& a, double** kin_o, void** iin_o, double
     }
     if (a.bk_R != kTile)
         LAUNCH(ctx, K_SPLITTERS, k_sample_runs<u64>, dim3((unsigned)a.bk_k, py), dim3(256), 0, (const u64*)rin, M, a.bk_R, a.samp);
-    const int S = a.bk_k * (int)(a.bk_R / 64);
-    const size_t lds_spl = (size_t)S * 12 + (size_t)(a.bk_B + 1) * 16 + (size_t)(a.bk_B + 1) * a.bk_k * 4 + 64;
-    if (lds_spl > 60 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_splitters<u64>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spl));
-    LAUNCH(ctx, K_SPLITTERS, k_splitters<u64>, dim3(py), dim3(1024), lds_spl, (const u64*)rin, (const double*)a.samp,
-           M, a.bk_k, a.bk_B, a.bk_D, a.bk_R, a.cut, a.boff);
+    {
+        const int rc = launch_splitters<u64>(ctx, a, (const u64*)rin);
+        if (rc) return rc;
+    }
     const unsigned pgrp = (unsigned)((pc + 7) / 8 * 8);
     LAUNCH(ctx, K_BUCKET_MERGE, (k_bucket_merge32<MNT, MVT>), dim3(pgrp * (unsigned)a.bk_B), dim3(MNT), rec_lds_bytes(kTile) + 512,
            (const u64*)rin, rout, M, a.bk_k, a.bk_B, (const u32*)a.cut, (const u32*)a.boff,
@@ -1000,13 +1020,29 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
     return MCR_OK;
 }
 
+// Waits for a slot's completion event.  The host polls the event for a while before it blocks in the runtime: a blocking
+// wait is woken through an interrupt and the scheduler, which costs a lone synchronous call (what reference.compare makes,
+// src/mcmc_ref/reference.py:107-122) some 20 - 40 us on top of its 0.3 ms; a pipelined caller seldom waits at all.
+int wait_event(mcr_ctx* ctx, hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return MCR_OK;
+        if (q != hipErrorNotReady) return fail(ctx, MCR_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        if ((spin & 63) == 63 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;
+    }
+    HIP_TRY(ctx, hipEventSynchronize(ev));
+    return MCR_OK;
+}
+
 // Waits for the OLDEST outstanding enqueue only and delivers its results; the others keep running.
 int wait_one_impl(mcr_ctx* ctx)
 {
     if (ctx->order.empty()) return MCR_OK;
     const int si = ctx->order.front();
     Slot& s = ctx->slots[si];
-    HIP_TRY(ctx, hipEventSynchronize(s.done));
+    { const int rc = wait_event(ctx, s.done); if (rc) return rc; }
     const int rc = unpack_slot(ctx, s);
     s.busy = false;
     ctx->order.erase(ctx->order.begin());
@@ -1016,6 +1052,9 @@ int wait_one_impl(mcr_ctx* ctx)
 
 int wait_impl(mcr_ctx* ctx)
 {
+    // every slot in flight records its event behind its last copy on its lane: waiting for the events (polled, see
+    // wait_event) leaves every lane idle; the stream synchronisations below then return at once
+    for (int si : ctx->order) { const int rc = wait_event(ctx, ctx->slots[si].done); if (rc) return rc; }
     for (hipStream_t st : ctx->lane_stream) if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
     use_lane(ctx, 0);
     prof_resolve(ctx);
@@ -1134,6 +1173,7 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_GRAPH")) ctx->graph_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
     if (const char* env = getenv("MCR_FFT")) ctx->fft_on = atoi(env) != 0;
+    if (const char* env = getenv("MCR_SPLITTERS_PAIRWISE")) ctx->splitters_pairwise = atoi(env) != 0;
     if (const char* env = getenv("MCR_DBG_LDS_PAD")) {
         unsigned long t = 0, b = 0, f = 0;
         if (sscanf(env, "%lu,%lu,%lu", &t, &b, &f) >= 1) { ctx->dbg_lds_pad[0] = t; ctx->dbg_lds_pad[1] = b; ctx->dbg_lds_pad[2] = f; }

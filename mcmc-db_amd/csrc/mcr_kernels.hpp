@@ -870,7 +870,26 @@ __global__ __launch_bounds__(NT) void k_merge(const KT* __restrict__ kin, const 
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxBucketTiles = 16;
 
-template <typename KT>      // KT = double (sorted keys) or u64 (sorted f32 records, mcr_sort32.hpp)
+// The LDS of k_splitters: S samples + splitter tables + cut table, then (MVT > 0) the merge area of the sample ranking.
+__host__ __device__ inline size_t splitters_base_bytes(int S, int B, int k, int mvt)     // tables in front of the merge area, 16-byte aligned
+{
+    const size_t base = (size_t)S * (mvt > 0 ? 8 : 12) + (size_t)(B + 1) * 16 + (size_t)(B + 1) * k * 4 + 64;   // (no rank array in merge mode)
+    return (base + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t splitters_lds_bytes(int S, int B, int k, int mvt)
+{
+    return splitters_base_bytes(S, B, k, mvt) + (mvt > 0 ? (size_t)(1024 * mvt + 16) * 10 : 0);
+}
+
+// MVT = 0: few samples (S <= 1024: pooled arrays of up to 16 tiles, the C1 and corpus shapes) -- every (sample, other
+//          run) pair is one bisection, the pooled ranks add up with LDS atomics.
+// MVT > 0: many samples (runs pre-merged to 8192 .. 32768 draws: 128 .. 512 samples each, up to 8192 in all; the stress
+//          shape ranks 6 656) -- the k sorted sample lists are MERGED in the LDS, ceil(log2 k) merge-path rounds of
+//          1024 threads x MVT outputs carrying (value, origin) pairs; a sample's place in the merged list IS its pooled
+//          rank in the strict order (value, run, position), since the merges are stable and the runs enter in order.
+//          ~190 LDS round trips per thread on the stress shape instead of 6.5 samples x 12 runs x 9 probes = 700
+//          (k_splitters was 12.4 ms of its 216 ms step, and the first kernel of the long-chain profile: VERDICT r3 item 8).
+template <typename KT, int MVT>      // KT = double (sorted keys) or u64 (sorted f32 records, mcr_sort32.hpp)
 __global__ __launch_bounds__(1024) void k_splitters(const KT* __restrict__ keys,
                                                     const double* __restrict__ samp, i64 M, int k, int B,
                                                     int D, i64 R, u32* __restrict__ cut, u32* __restrict__ boff)
@@ -881,15 +900,59 @@ __global__ __launch_bounds__(1024) void k_splitters(const KT* __restrict__ keys,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sv = reinterpret_cast<double*>(smem);    // S samples
     double* splv = sv + S;                           // B splitter values
-    int* srank = reinterpret_cast<int*>(splv + B + 1);   // S pooled ranks
-    int* splt = srank + S;                           // B splitter run
+    int* srank = reinterpret_cast<int*>(splv + B + 1);   // S pooled ranks (MVT == 0 only)
+    int* splt = srank + (MVT > 0 ? 0 : S);           // B splitter run
     int* splp = splt + B + 1;                        // B splitter position in run
     u32* scut = reinterpret_cast<u32*>(splp + B + 1);    // (B+1) * k cuts
     const int tid = threadIdx.x;
     const i64 p = blockIdx.x;
     const KT* kp = keys + p * M;
-    for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; srank[i] = i % SPT; }
+    for (int i = tid; i < S; i += NTS) { sv[i] = samp[p * S + i]; if (MVT == 0) srank[i] = i % SPT; }
     for (int b = tid; b <= B; b += NTS) splt[b] = -1;      // -1 = splitter b not found (only with NaN / Inf draws)
+    if (MVT > 0) {
+        constexpr int VT = MVT > 0 ? MVT : 1;
+        static_assert(MVT == 0 || 64 % VT == 0, "a thread's VT outputs must not straddle two pairs of runs (run lengths are multiples of 64)");
+        constexpr int SP = NTS * VT;                           // merge slots: the samples, then +inf pads (S <= SP)
+        double* mk = reinterpret_cast<double*>(smem + splitters_base_bytes(S, B, k, MVT));                   // [SP + 16] keys, pos16-swizzled
+        unsigned short* mi = reinterpret_cast<unsigned short*>(mk + SP + 16);                                // [SP + 16] origin = run * SPT + index
+        for (int e = tid; e < SP + 16; e += NTS) {
+            mk[pos16(e)] = (e < S) ? samp[p * S + e] : INFINITY;
+            mi[e] = (unsigned short)(e < S ? e : 0xFFFF);
+        }
+        __syncthreads();
+        const int chunk0 = tid * VT;
+        for (int g = SPT; g < SP; g <<= 1) {                   // runs of g slots merge in pairs (SP is a multiple of SPT)
+            double kk[VT]; int srcs[VT]; unsigned short ids[VT];
+            const int a0 = chunk0 / (2 * g) * (2 * g);
+            const int a1 = (a0 + g < SP) ? a0 + g : SP, b1 = (a0 + 2 * g < SP) ? a0 + 2 * g : SP;
+            const int na = a1 - a0, nb = b1 - a1, diag = chunk0 - a0;
+            const bool moved = nb > 0;
+            if (moved) {
+                auto A = [&](int i) { return mk[pos16(a0 + i)]; };
+                auto Bf = [&](int j) { return mk[pos16(a1 + j)]; };
+                const int ai = merge_path32(A, na, Bf, nb, diag);
+                serial_merge<VT>(mk, a0, na, a1, nb, ai, diag - ai, VT, kk, srcs);
+#pragma unroll
+                for (int i = 0; i < VT; ++i) ids[i] = mi[srcs[i]];
+            }
+            __syncthreads();
+            if (moved) {
+#pragma unroll
+                for (int i = 0; i < VT; ++i) { mk[pos16(chunk0 + i)] = kk[i]; mi[chunk0 + i] = ids[i]; }
+            }
+            __syncthreads();
+        }
+        // the sample at merged place r = b D - 1 is splitter b
+        for (int b = 1 + tid; b < B; b += NTS) {
+            const int r = b * D - 1;
+            if (r < SP) {
+                const double v = mk[pos16(r)];
+                const int i = mi[r];
+                if (v < INFINITY && i < S) { splv[b] = v; splt[b] = i / SPT; splp[b] = 64 * (i % SPT) + 63; }
+            }
+        }
+        __syncthreads();
+    } else {
     __syncthreads();
     // pooled rank of every finite sample = own index + samples of every other run below it;
     // one (sample, other run) pair per thread step
@@ -914,6 +977,7 @@ __global__ __launch_bounds__(1024) void k_splitters(const KT* __restrict__ keys,
         }
     }
     __syncthreads();
+    }
     // Non-finite draws (the call will be rejected with MCR_ENONFINITE) break the ordering the splitters rely on:
     // leave an EMPTY partition behind, so that no later kernel walks cut tables made of garbage.
     {
