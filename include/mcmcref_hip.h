@@ -236,13 +236,14 @@ int mcr_fill_synthetic_at(mcr_ctx* ctx, void* draws_dev, int dtype, int64_t C, i
  * Ranks must agree on a 128-byte id: rank 0 calls mcr_comm_unique_id and hands the bytes to the others
  * by any means (mcmc_ref_hip.shard uses a file keyed on MASTER_ADDR / MASTER_PORT), then every rank
  * calls mcr_comm_init (collective).  All buffers are host pointers; calls are synchronous.
- * EVERY collective has a deadline: the communicator is created non-blocking (ncclCommInitRankConfig,
- * blocking = 0) and init / all-gather / all-reduce / barrier poll ncclCommGetAsyncError and the stream
- * against MCR_COMM_TIMEOUT_S (default 300).  A peer that never arrives or dies -- the reference's
- * loop simply continues past a failed recipe, src/mcmc_ref/generate.py:77-96 -- ends the call with
- * MCR_ECOMM naming the call and the rank after that time instead of blocking for ever; the
- * communicator is aborted (ncclCommAbort) and every later call on it fails at once.
- * MCR_COMM_BLOCKING=1 selects the plain blocking calls (no deadline); mcr_comm_has_deadline tells.
+ * EVERY collective has a deadline: ncclCommInitRank runs on a helper thread the caller watches, and the
+ * waits for all-gather / all-reduce / barrier poll the communicator's stream and ncclCommGetAsyncError
+ * against MCR_COMM_TIMEOUT_S (default 300).  A peer that never arrives or dies -- the reference's loop
+ * simply continues past a failed recipe, src/mcmc_ref/generate.py:77-96 -- ends the call with MCR_ECOMM
+ * naming the call and the rank after that time instead of blocking for ever; the communicator is
+ * aborted (ncclCommAbort) and every later call on it fails at once.  MCR_COMM_NONBLOCKING=1 creates
+ * the communicator with ncclCommInitRankConfig(blocking = 0); MCR_COMM_BLOCKING=1 switches the
+ * deadlines off (plain blocking calls); mcr_comm_has_deadline tells.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct mcr_comm mcr_comm;
 #define MCR_COMM_ID_BYTES 128
@@ -252,7 +253,7 @@ int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** 
 void mcr_comm_free(mcr_comm* comm);
 int mcr_comm_world(const mcr_comm* comm);
 int mcr_comm_rank(const mcr_comm* comm);
-int mcr_comm_has_deadline(const mcr_comm* comm); /* 1: non-blocking communicator, every wait is bounded */
+int mcr_comm_has_deadline(const mcr_comm* comm); /* 1: every wait on this communicator is bounded */
 /* ncclAllGather: every rank sends `count` doubles and receives world * count doubles in rank order. */
 int mcr_comm_all_gather(mcr_comm* comm, const double* send, int64_t count, double* recv);
 /* ncclAllReduce in place over n doubles; op: 0 = sum, 1 = max, 2 = min (max-over-ranks clock, all-valid flag). */

@@ -1864,7 +1864,8 @@ struct mcr_comm {
     hipStream_t stream = nullptr;
     int world = 1, rank = 0;
     void* dbuf = nullptr; size_t dbytes = 0;      // device staging (send block + receive blocks)
-    bool nonblocking = false;                     // communicator created with config.blocking = 0: every wait has a deadline
+    bool deadline = true;                         // every wait is bounded by timeout_s (MCR_COMM_BLOCKING=1 switches that off)
+    bool nonblocking = false;                     // MCR_COMM_NONBLOCKING=1: communicator created with config.blocking = 0
     bool dead = false;                            // aborted after a deadline or an asynchronous error
     double timeout_s = 300.0;                     // MCR_COMM_TIMEOUT_S
 };
@@ -1886,12 +1887,19 @@ int comm_buf(mcr_comm* c, size_t bytes)
 
 // A DEADLINE ON EVERY COLLECTIVE.  The ranks are separate processes; one that dies after the
 // rendezvous (the reference's generate loop carries on past a failed recipe, src/mcmc_ref/generate.py:77-96 -- a sharded
-// one must at least not hang on it) would leave its peers inside ncclCommInitRank / ncclAllGather for ever.  The
-// communicator is therefore created NON-BLOCKING (ncclCommInitRankConfig, config.blocking = 0): every RCCL call returns
-// at once, and comm_wait polls ncclCommGetAsyncError / hipStreamQuery against MCR_COMM_TIMEOUT_S (default 300 s; the
-// first ncclCommInitRank of a node can take tens of seconds).  On expiry, or on an asynchronous RCCL error, the
-// communicator is aborted (ncclCommAbort: its kernels and its bootstrap sockets are torn down, nothing stays blocked),
-// marked dead, and the call returns MCR_ECOMM naming the call, the rank and the time; every later call on it fails at once.
+// one must at least not hang on it) would leave its peers inside ncclCommInitRank / ncclAllGather for ever.  So:
+//   * ncclCommInitRank runs on a helper thread and the caller only watches the clock (a rank whose peers never come does
+//     not return from it, and on RCCL 2.27.7 neither does an abort of it);
+//   * the collectives are enqueued on the communicator's stream as usual (the RCCL call returns once its kernel is in the
+//     stream) and the wait for that stream is a poll of hipStreamQuery + ncclCommGetAsyncError against
+//     MCR_COMM_TIMEOUT_S (default 300 s; the first init of a node can take tens of seconds) instead of a
+//     hipStreamSynchronize;
+//   * on expiry, or on an asynchronous RCCL error, the communicator is aborted (ncclCommAbort, itself bounded: it tears
+//     down the stuck kernel and the proxy), marked dead, and the call returns MCR_ECOMM naming the call, the rank and the
+//     time; every later call on it fails at once.
+// The communicator itself is the ordinary BLOCKING one (what every RCCL application runs; its first world > 1 run here
+// is the driver's); MCR_COMM_NONBLOCKING=1 creates it with ncclCommInitRankConfig(blocking = 0) instead, where the RCCL
+// calls themselves return ncclInProgress and are polled too.  MCR_COMM_BLOCKING=1: no deadlines at all (round 3).
 using comm_clock = std::chrono::steady_clock;
 
 // ncclCommAbort with a bound of its own: measured on RCCL 2.27.7, aborting a communicator whose ncclCommInitRank is still
@@ -1944,13 +1952,13 @@ int comm_wait(mcr_comm* c, const char* what, bool stream)
         }
     }
     if (!stream) return MCR_OK;
-    if (!c->nonblocking) { HIP_TRY(c->ctx, hipStreamSynchronize(c->stream)); return MCR_OK; }
+    if (!c->deadline) { HIP_TRY(c->ctx, hipStreamSynchronize(c->stream)); return MCR_OK; }
     for (;;) {
         const hipError_t q = hipStreamQuery(c->stream);
         if (q == hipSuccess) return MCR_OK;
         if (q != hipErrorNotReady) return fail(c->ctx, MCR_EHIP, "%s: hipStreamQuery failed: %s", what, hipGetErrorString(q));
         ncclResult_t st = ncclSuccess;
-        if (a->CommGetAsyncError(c->nccl, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) {
+        if (a->CommGetAsyncError && a->CommGetAsyncError(c->nccl, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress) {
             char why[160];
             snprintf(why, sizeof why, "asynchronous RCCL error: %s", a->GetErrorString ? a->GetErrorString(st) : "?");
             return comm_abort(c, what, why);
@@ -1987,13 +1995,15 @@ int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** 
     c->ctx = ctx; c->world = world; c->rank = rank;
     if (const char* env = getenv("MCR_COMM_TIMEOUT_S")) { const double v = atof(env); if (v > 0.0) c->timeout_s = v; }
     const char* blk = getenv("MCR_COMM_BLOCKING");
-    c->nonblocking = a->nonblocking() && !(blk && atoi(blk) != 0);
+    const char* nbl = getenv("MCR_COMM_NONBLOCKING");
+    c->deadline = !(blk && atoi(blk) != 0);
+    c->nonblocking = c->deadline && a->nonblocking() && nbl && atoi(nbl) != 0;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(ctx, MCR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     // collective: every rank of the world calls it
-    if (c->nonblocking) {
+    if (c->deadline) {
         // The whole init runs on a helper thread and THIS thread only watches the clock: on RCCL 2.27.7 neither the init of a
         // rank whose peers never come nor an abort of it is guaranteed to return, and the caller must get its error anyway.
         struct InitJob {
@@ -2003,14 +2013,19 @@ int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** 
         };
         auto job = std::make_shared<InitJob>();
         const int dev = ctx->device;
-        std::thread([a, job, dev, world, uid, rank]() {
+        const bool nonblocking = c->nonblocking;
+        std::thread([a, job, dev, world, uid, rank, nonblocking]() {
             hipSetDevice(dev);
-            ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-            cfg.blocking = 0;
             ncclComm_t h = nullptr;
-            job->r = a->CommInitRankConfig(&h, world, uid, rank, &cfg);
+            if (nonblocking) {
+                ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+                cfg.blocking = 0;
+                job->r = a->CommInitRankConfig(&h, world, uid, rank, &cfg);
+            } else {
+                job->r = a->CommInitRank(&h, world, uid, rank);          // returns when every rank has arrived -- or never
+            }
             job->nccl.store(h, std::memory_order_release);
-            if ((job->r == ncclSuccess || job->r == ncclInProgress) && h) {
+            if (nonblocking && (job->r == ncclSuccess || job->r == ncclInProgress) && h) {
                 ncclResult_t st = ncclInProgress;
                 int spins = 0;
                 while (!job->cancel.load(std::memory_order_acquire)) {
@@ -2033,8 +2048,8 @@ int mcr_comm_init(mcr_ctx* ctx, const void* id, int world, int rank, mcr_comm** 
             bounded_abort(job->nccl.load(std::memory_order_acquire));
             rc = fail(ctx, MCR_ECOMM, "ncclCommInitRank: rank %d of %d gave up: a peer did not arrive before the deadline "
                       "(MCR_COMM_TIMEOUT_S = %g s); the communicator was aborted", rank, world, c->timeout_s);
-        } else if (job->r != ncclSuccess && job->r != ncclInProgress) rc = comm_fail(ctx, "ncclCommInitRankConfig", job->r);
-        else if (!job->nccl.load()) rc = fail(ctx, MCR_ECOMM, "ncclCommInitRankConfig returned no communicator");
+        } else if (job->r != ncclSuccess && job->r != ncclInProgress) rc = comm_fail(ctx, "ncclCommInitRank", job->r);
+        else if (!job->nccl.load()) rc = fail(ctx, MCR_ECOMM, "ncclCommInitRank returned no communicator");
         else if (job->async != ncclSuccess) { bounded_abort(job->nccl.load()); rc = comm_fail(ctx, "ncclCommInitRank (asynchronous)", job->async); }
         if (rc) { hipStreamDestroy(c->stream); delete c; return rc; }
         c->nccl = job->nccl.load();
@@ -2052,7 +2067,7 @@ void mcr_comm_free(mcr_comm* c)
     hipSetDevice(c->ctx->device);
     mcr::comm::Api* a = mcr::comm::api();
     if (c->nccl && !c->dead) {
-        if (c->nonblocking) {
+        if (c->deadline) {
             if (comm_wait(c, "mcr_comm_free", true) == MCR_OK && c->nccl) {
                 a->CommDestroy(c->nccl);            // (returns ncclInProgress on a non-blocking communicator: finalisation goes on inside RCCL)
             }
@@ -2068,7 +2083,7 @@ void mcr_comm_free(mcr_comm* c)
 
 int mcr_comm_world(const mcr_comm* c) { return c ? c->world : -1; }
 int mcr_comm_rank(const mcr_comm* c) { return c ? c->rank : -1; }
-int mcr_comm_has_deadline(const mcr_comm* c) { return (c && c->nonblocking) ? 1 : 0; }
+int mcr_comm_has_deadline(const mcr_comm* c) { return (c && c->deadline) ? 1 : 0; }
 
 // THE collective of the path: every rank contributes `count` doubles, every rank receives world * count doubles in
 // rank order (ncclAllGather over xGMI).  Host pointers; staged through a small device buffer on the communicator's stream.

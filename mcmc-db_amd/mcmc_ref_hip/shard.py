@@ -203,8 +203,8 @@ class Communicator:
 
     @property
     def has_deadline(self) -> bool:
-        """True: the RCCL communicator is non-blocking and every collective gives up after MCR_COMM_TIMEOUT_S (default
-        300 s) with an McrError(MCR_ECOMM) instead of waiting for a dead peer for ever (mcr_comm_has_deadline)."""
+        """True: every collective on this communicator gives up after MCR_COMM_TIMEOUT_S (default 300 s) with an
+        McrError(MCR_ECOMM) instead of waiting for a dead peer for ever (mcr_comm_has_deadline)."""
         return bool(self.ctx.lib.mcr_comm_has_deadline(self.handle))
 
     def all_gather(self, arr: np.ndarray) -> np.ndarray:

@@ -39,15 +39,19 @@ def test_bench_one_rank_over_rccl(workload):
     assert out["metric"] == "validated param-draws/sec"
 
 
-def test_communicator_collectives_one_rank(tmp_path, monkeypatch):
-    """mcr_comm_* directly: a world of one over RCCL (ncclAllGather / ncclAllReduce on this GPU), gather_records on top."""
+@pytest.mark.parametrize("nonblocking", ["0", "1"])
+def test_communicator_collectives_one_rank(tmp_path, monkeypatch, nonblocking):
+    """mcr_comm_* directly: a world of one over RCCL (ncclAllGather / ncclAllReduce on this GPU), gather_records on top.
+    Both communicator modes: the default (blocking communicator, init on a watched helper thread, polled stream waits) and
+    MCR_COMM_NONBLOCKING=1 (ncclCommInitRankConfig with blocking = 0)."""
     import numpy as np
     from mcmc_ref_hip import _ffi, shard
+    monkeypatch.setenv("MCR_COMM_NONBLOCKING", nonblocking)
     monkeypatch.setenv("MCR_COMM_DIR", str(tmp_path))
     monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     with _ffi.Context(0) as ctx, shard.Communicator(ctx, world=1, rank=0) as comm:
         assert (comm.world, comm.rank) == (1, 0)
-        assert comm.has_deadline                                    # non-blocking communicator: every wait below is bounded
+        assert comm.has_deadline                                    # every wait below is bounded by MCR_COMM_TIMEOUT_S
         assert list(tmp_path.iterdir()) == []                       # rank 0 removed the id file after the init
         x = np.arange(48.0).reshape(3, 16)
         assert np.array_equal(comm.all_gather(x), x[None])
@@ -88,12 +92,14 @@ os._exit(0)     # RCCL 2.27.7 does not return from aborting an init that waits f
 """
 
 
-def test_a_peer_that_never_arrives_ends_in_an_error_not_a_hang(tmp_path):
-    """ncclCommInitRank with a world of two and only this rank present.  The non-blocking communicator
-    gives up after MCR_COMM_TIMEOUT_S, aborts itself and returns MCR_ECOMM naming the call and the rank; the process goes
-    on (its context still computes).  Runs in a child with a hard limit so that a hang would fail, not stall, the suite."""
+@pytest.mark.parametrize("nonblocking", ["0", "1"])
+def test_a_peer_that_never_arrives_ends_in_an_error_not_a_hang(tmp_path, nonblocking):
+    """ncclCommInitRank with a world of two and only this rank present.  The call gives up after
+    MCR_COMM_TIMEOUT_S and returns MCR_ECOMM naming the call and the rank; the process goes on (its context still
+    computes).  Both communicator modes (the default blocking one under the watchdog, MCR_COMM_NONBLOCKING=1).  Runs in a
+    child with a hard limit so that a hang would fail, not stall, the suite."""
     from mcmc_ref_hip import _ffi
-    env = dict(os.environ, MCR_COMM_TIMEOUT_S="4")
+    env = dict(os.environ, MCR_COMM_TIMEOUT_S="4", MCR_COMM_NONBLOCKING=nonblocking)
     code = _ABSENT_PEER.format(root=str(ROOT), pkg=str(ROOT / "mcmc-db_amd"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=75, cwd=str(ROOT))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
