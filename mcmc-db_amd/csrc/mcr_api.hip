@@ -90,6 +90,9 @@ struct mcr_ctx {
     // Lanes = streams with a workspace each (MCR_LANES, default 4): consecutive enqueues rotate lanes, so the
     // tail of one call's kernels (partial last waves of workgroups) overlaps the next call's head.
     hipStream_t lane_stream[MCR_MAX_INFLIGHT] = {};
+    hipStream_t lane_aux[MCR_MAX_INFLIGHT] = {};      // second stream of a lane + its fork / join events (lone calls: run_pipeline)
+    hipEvent_t lane_fork[MCR_MAX_INFLIGHT] = {}, lane_join[MCR_MAX_INFLIGHT] = {};
+    bool fork_lone = true;                            // MCR_FORK=0: never fork
     void* lane_ws[MCR_MAX_INFLIGHT] = {};
     size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
     int lane = 0, n_lanes = 4;
@@ -201,6 +204,7 @@ void use_lane(mcr_ctx* ctx, int lane)
 }
 void sync_all(mcr_ctx* ctx)
 {
+    for (hipStream_t s : ctx->lane_aux) if (s) hipStreamSynchronize(s);     // (joined into the lane's stream in normal operation)
     for (hipStream_t s : ctx->lane_stream) if (s) hipStreamSynchronize(s);
 }
 
@@ -406,40 +410,51 @@ struct PipeIn {
     i64 bk_R = 0;
     i64 ntiles;
     bool do_diag = true;  // false: Backend.stats only (sort + order statistics + moments)
+    bool fork = false;    // lone call: the bulk half of the diagnostics on the lane's second stream (run_pipeline)
 };
 
-// Split R-hat + ESS: segment products, combine, flagged continuation (mcr_diag.hpp).
-int launch_diag(mcr_ctx* ctx, const PipeIn& a)
+// Tiers 1 and 2 of one kind (0 bulk, 1 folded) or of both (kind_sel < 0): segment products, combine, the flagged pairs'
+// lags 64..255 -- everything of the diagnostics that does not need the other kind.  On ctx->stream.
+int launch_diag_front(mcr_ctx* ctx, const PipeIn& a, int kind_sel)
 {
     // short chains (<= 1024 draws, e.g. the packaged corpus): half-size segments on 128-thread
     // workgroups, so twice as many of the latency-bound workgroups are resident per CU
     const bool small = a.nstage <= 1024;
     const int seg = small ? 1024 : kSeg;
     const int nseg = (int)((a.nstage + seg - 1) / seg);
-    const unsigned pk = (unsigned)(2 * a.pc);
+    const unsigned pk = (unsigned)((kind_sel < 0 ? 2 : 1) * a.pc), ky = kind_sel < 0 ? 2u : 1u;
     if (small) {
         LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<128, 1024, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
-               (const unsigned*)nullptr, a.rec);
+               (const unsigned*)nullptr, a.rec, kind_sel);
     } else {
         LAUNCH(ctx, K_ACOV_SEG, (k_acov_seg<256, kSeg, true>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
-               (const unsigned*)nullptr, a.rec);
+               (const unsigned*)nullptr, a.rec, kind_sel);
     }
-    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, 2), dim3(64u * (unsigned)(a.C < kCombineWaves ? a.C : kCombineWaves)), (size_t)6 * a.C * 8, (const u32*)a.zb,
+    LAUNCH(ctx, K_DIAG, k_diag_combine, dim3((unsigned)a.pc, ky), dim3(64u * (unsigned)(a.C < kCombineWaves ? a.C : kCombineWaves)), (size_t)6 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg, (const double*)a.rec, a.d_res, a.pc, a.more, a.state, a.chstate,
            a.long_count, a.long_list,       // (long_list doubles as k_tier3's per-pair counters)
-           ctx->rho_band, ctx->guard_count);
+           ctx->rho_band, ctx->guard_count, kind_sel);
     // tier 2 for pairs whose first negative rho lies beyond lag 63 (others exit at once)
     if (small) {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<128, 1024, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(128), 0,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
-               (const unsigned*)a.more, a.rec2);
+               (const unsigned*)a.more, a.rec2, kind_sel);
     } else {
         LAUNCH(ctx, K_ACOV_MORE, (k_acov_seg<256, kSeg, false>), dim3((unsigned)nseg, (unsigned)a.C, pk), dim3(256), 0,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C, a.n, a.nh, nseg,
-               (const unsigned*)a.more, a.rec2);
+               (const unsigned*)a.more, a.rec2, kind_sel);
     }
+    return MCR_OK;
+}
+
+// Split R-hat + ESS (mcr_diag.hpp): the joint part -- tier 2's combine (+ finalize), tier 3.
+int launch_diag(mcr_ctx* ctx, const PipeIn& a)
+{
+    const bool small = a.nstage <= 1024;
+    const int seg = small ? 1024 : kSeg;
+    const int nseg = (int)((a.nstage + seg - 1) / seg);
     const bool fused_tier3 = !a.fft.on && a.n <= 16384 && 2 * a.pc <= kTier3MaxPairs;     // k_tier3: one launch for the whole tier
     LAUNCH(ctx, K_DIAG2, k_diag_combine2, dim3((unsigned)a.pc, 2), dim3(1024), (size_t)2 * a.C * 8, (const u32*)a.zb,
            (const u32*)a.zt, (const double*)a.ztab, a.M, a.d_off, a.C,
@@ -726,6 +741,21 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
         if (!ranked)
             LAUNCH(ctx, K_RANK_Z, k_rank_z, dim3((unsigned)((M + 255) / 256), py), dim3(256), 0,
                    (const double*)kin, (const u32*)iin, M, a.zb);       // no bucket path only beyond 512 K draws: u32 positions
+        // A LONE call (nothing else in flight on the context: what reference.compare makes) forks here: the bulk half of
+        // tiers 1 and 2 needs only the bulk rank codes, which exist now, so it runs on the lane's second stream UNDER the fold
+        // kernel, and the two halves join in front of combine2 -- ~35 us off the critical path of a 0.3 ms call.  A pipelined
+        // caller keeps the single stream: its lanes are full anyway, and three more launches per call would only cost.
+        const bool fork = a.fork && a.C >= 2 && ctx->lane_aux[ctx->lane] != nullptr;
+        hipStream_t main_stream = ctx->stream;
+        if (fork) {
+            HIP_TRY(ctx, hipEventRecord(ctx->lane_fork[ctx->lane], main_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->lane_aux[ctx->lane], ctx->lane_fork[ctx->lane], 0));
+            ctx->stream = ctx->lane_aux[ctx->lane];
+            const int rc = launch_diag_front(ctx, a, 0);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            HIP_TRY(ctx, hipEventRecord(ctx->lane_join[ctx->lane], ctx->lane_aux[ctx->lane]));
+        }
         // 5+6. fold: one merge of the two monotone halves around the median, fused with ranks -> z
         const unsigned fgrid = (unsigned)((pc + 7) / 8 * 8) * (unsigned)((M + (kTile - 64) - 1) / (kTile - 64));   // 4032 outputs per fold workgroup
         {
@@ -734,7 +764,12 @@ int run_pipeline(mcr_ctx* ctx, PipeIn& a)
             if (rc) return rc;
         }
         // 7. R-hat + ESS (+ the finalize step, inside k_diag_combine2)
-        if (a.C >= 2) return launch_diag(ctx, a);
+        if (a.C >= 2) {
+            const int rc = launch_diag_front(ctx, a, fork ? 1 : -1);
+            if (rc) return rc;
+            if (fork) HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->lane_join[ctx->lane], 0));
+            return launch_diag(ctx, a);
+        }
     }
     // 8. finalize (calls without diagnostics, single chains)
     LAUNCH(ctx, K_FINALIZE, k_finalize, dim3((unsigned)((pc + 63) / 64)), dim3(64), 0, (const double*)a.part,
@@ -944,6 +979,9 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.boff = cv.take<u32>((size_t)pc * (wp.bk_B + 1));
                 a.bk_B = wp.bk_B; a.bk_D = wp.bk_D; a.bk_k = wp.bk_k; a.bk_R = wp.bk_R;
                 a.do_diag = do_diag;
+                // (a graph capture or the per-kernel event pairs of the profiling mode keep the single stream)
+                a.fork = ctx->fork_lone && ctx->n_inflight == 0 && !ctx->prof && !ctx->graph_on && P <= pcmax &&
+                         (double)M * (double)pc <= 8e6;
                 a.fft = fp; a.tw1 = tw1; a.tw2 = tw2;
                 if (fp.on) {
                     const size_t Nf = (size_t)1 << fp.logN;
@@ -1054,7 +1092,9 @@ int wait_impl(mcr_ctx* ctx)
 {
     // every slot in flight records its event behind its last copy on its lane: waiting for the events (polled, see
     // wait_event) leaves every lane idle; the stream synchronisations below then return at once
-    for (int si : ctx->order) { const int rc = wait_event(ctx, ctx->slots[si].done); if (rc) return rc; }
+    // (slots filled by mcr_diagnose_chains carry no event of their own: the stream synchronisation waits for those)
+    for (int si : ctx->order)
+        if (ctx->slots[si].done) { const int rc = wait_event(ctx, ctx->slots[si].done); if (rc) return rc; }
     for (hipStream_t st : ctx->lane_stream) if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
     use_lane(ctx, 0);
     prof_resolve(ctx);
@@ -1159,10 +1199,18 @@ int mcr_init(int device, mcr_ctx** out)
     e = hipSetDevice(device);
     for (int l = 0; l < ctx->n_lanes && e == hipSuccess; ++l)
         e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
+    for (int l = 0; l < ctx->n_lanes && e == hipSuccess; ++l) {
+        e = hipStreamCreateWithFlags(&ctx->lane_aux[l], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_fork[l], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_join[l], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
         for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
+        for (hipStream_t st : ctx->lane_aux) if (st) hipStreamDestroy(st);
+        for (hipEvent_t ev : ctx->lane_fork) if (ev) hipEventDestroy(ev);
+        for (hipEvent_t ev : ctx->lane_join) if (ev) hipEventDestroy(ev);
         delete ctx;
         return fail(nullptr, MCR_EHIP, "device %d init failed: %s", device, hipGetErrorString(e));
     }
@@ -1174,6 +1222,7 @@ int mcr_init(int device, mcr_ctx** out)
     if (const char* env = getenv("MCR_F32_RECORDS")) ctx->f32_records = atoi(env) != 0;
     if (const char* env = getenv("MCR_FFT")) ctx->fft_on = atoi(env) != 0;
     if (const char* env = getenv("MCR_SPLITTERS_PAIRWISE")) ctx->splitters_pairwise = atoi(env) != 0;
+    if (const char* env = getenv("MCR_FORK")) ctx->fork_lone = atoi(env) != 0;
     if (const char* env = getenv("MCR_DBG_LDS_PAD")) {
         unsigned long t = 0, b = 0, f = 0;
         if (sscanf(env, "%lu,%lu,%lu", &t, &b, &f) >= 1) { ctx->dbg_lds_pad[0] = t; ctx->dbg_lds_pad[1] = b; ctx->dbg_lds_pad[2] = f; }
@@ -1221,6 +1270,9 @@ void mcr_free(mcr_ctx* ctx)
     if (ctx->fs_arena) hipFree(ctx->fs_arena);
     if (ctx->pq_pin) hipHostFree(ctx->pq_pin);
     for (hipStream_t st : ctx->lane_stream) if (st) hipStreamDestroy(st);
+    for (hipStream_t st : ctx->lane_aux) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : ctx->lane_fork) if (ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->lane_join) if (ev) hipEventDestroy(ev);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }

@@ -160,7 +160,7 @@ template <int NT, int SEG, bool FIRST>
 __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, const u32* __restrict__ zt,
                                                  const double* __restrict__ ztab, i64 M,
                                                  const i64* __restrict__ off, int C, i64 n, i64 nh, int nseg,
-                                                 const unsigned* __restrict__ more, double* __restrict__ rec)
+                                                 const unsigned* __restrict__ more, double* __restrict__ rec, int kind_sel)
 {
     constexpr int NW = NT / kWave;
     static_assert(SEG % 128 == 0, "spans of the widest tile are 128 draws");
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x, c = blockIdx.y;
-    const i64 pk = blockIdx.z, p = pk >> 1;
+    // kind_sel < 0: grid.z = 2 P, both kinds in one launch; 0 / 1: grid.z = P, this kind only (a lone call runs the bulk
+    // half on a second stream under the fold kernel: launch_diag)
+    const i64 pk = (kind_sel < 0) ? (i64)blockIdx.z : 2 * (i64)blockIdx.z + kind_sel, p = pk >> 1;
     const int kind = (int)(pk & 1);
     if (!FIRST && more[pk] == 0u) return;
     const u32* zc = (kind ? zt : zb) + p * M + off[c];     // rank codes; z = ztab[code]
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
                                                      double* __restrict__ res, i64 P, unsigned* __restrict__ more,
                                                      double* __restrict__ state, double* __restrict__ chstate,
                                                      unsigned* __restrict__ long_count, unsigned* __restrict__ pair_done,
-                                                     double band, unsigned* __restrict__ guard_count)
+                                                     double band, unsigned* __restrict__ guard_count, int kind_sel)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* cm = reinterpret_cast<double*>(smem);   // C   chain means
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     __shared__ double wcov[kCombineWaves][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = (int)(blockDim.x >> 6);
     const i64 p = blockIdx.x;
-    const int kind = blockIdx.y;
+    const int kind = (kind_sel < 0) ? (int)blockIdx.y : kind_sel;      // grid (P, 2), or (P, 1) for one kind
     const i64 pk = p * 2 + kind;
     const u32* z = (kind ? zt : zb) + p * M;
     const int f_rhat = kind ? R_RHAT_TAIL : R_RHAT_BULK;

@@ -1,25 +1,24 @@
 #!/usr/bin/env python3
-"""Single-call latencies: host-buffer boundary (PCIe-inclusive) vs device-resident, C1 and C0 shapes."""
-import os, sys, time
+"""Single-call latencies: host-buffer boundary (PCIe-inclusive) vs device-resident, C1 and C0 shapes; MCR_FORK=0/1."""
+import os, sys, time, statistics
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "mcmc-db_amd")]
 from mcmc_ref_hip import _ffi, synth
 ctx = _ffi.Context(0)
-for name, (C, N, P) in {"C1 4x10000x100": (4, 10000, 100), "C0 4x1000x10": (4, 1000, 10)}.items():
+for name, (C, N, P) in {"C1 4x10000x100": (4, 10000, 100), "C0 4x1000x10": (4, 1000, 10), "corpus 10x1000x45": (10, 1000, 45)}.items():
     x = synth.c1_model(C, N, P)
     t = ctx.upload(x, "pcn")
-    for _ in range(3):
+    for _ in range(5):
         ctx.summarize(x); ctx.summarize(t)
-    n = 30
-    t0 = time.perf_counter()
-    for _ in range(n): ctx.summarize(x)
-    host = (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for _ in range(n): ctx.summarize(t)
-    dev = (time.perf_counter() - t0) / n
-    pd = C * N * P
-    print(f"{name}: host-buffer call {host*1e3:.3f} ms ({pd/host/1e9:.2f} G pd/s incl. H2D of {x.nbytes/1e6:.1f} MB), "
-          f"device-resident synchronous call {dev*1e3:.3f} ms ({pd/dev/1e9:.2f} G pd/s)", flush=True)
+    def med(fn, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), min(ts)
+    host, hmin = med(lambda: ctx.summarize(x), 30)
+    dev, dmin = med(lambda: ctx.summarize(t), 60)
+    print(f"fork={os.environ.get('MCR_FORK','1')} {name}: host-buffer call {host*1e6:.0f} us (min {hmin*1e6:.0f}), "
+          f"device-resident synchronous call {dev*1e6:.0f} us (min {dmin*1e6:.0f})", flush=True)
     t.free()
