@@ -345,6 +345,34 @@ def test_sample_ranking_modes_agree_on_many_parameters(monkeypatch):
         pair.close(); merge.close()
 
 
+def test_lone_calls_fork_and_pipelined_calls_do_not_and_both_agree(monkeypatch):
+    """A lone synchronous call runs the bulk half of the diagnostics' tiers 1 and 2 on the lane's second stream under the
+    fold kernel (round 4); pipelined calls and MCR_FORK=0 keep one stream.  Same bits either way, in any interleaving."""
+    from mcmc_ref_hip import _ffi, synth
+    monkeypatch.setenv("MCR_FORK", "0")
+    plain = _ffi.Context(0)
+    monkeypatch.delenv("MCR_FORK")
+    forked = _ffi.Context(0)
+    rng = np.random.default_rng(4)
+    try:
+        shapes = [(4, 10000, 12), (10, 1000, 45), (4, 1000, 3), (2, 50, 5), (4, 30000, 2)]
+        xs = [synth.c1_model(C, N, P, seed=5 + i) for i, (C, N, P) in enumerate(shapes)]
+        xs.append(np.cumsum(rng.normal(size=(6, 4, 5000)), axis=2) * 0.01)          # tier 3 behind the join
+        for x in xs:
+            a = plain.summarize(x, "pcn", min_chains=2)
+            t = forked.upload(x, "pcn")
+            b = forked.summarize(t, min_chains=2)                                     # lone: forks
+            bufs = [forked.enqueue(t, min_chains=2) for _ in range(5)]                # pipelined: the first forks, the rest do not
+            forked.wait()
+            c = forked.summarize(t, min_chains=2)                                     # lone again
+            t.free()
+            for r in [b, c] + [q.result() for q in bufs]:
+                for k in a:
+                    assert np.array_equal(a[k], r[k], equal_nan=True), (x.shape, k)
+    finally:
+        plain.close(); forked.close()
+
+
 def test_sticky_chains_continuation_paths(ctx, oracle):
     """AR(1) with phi = 0.995: the first negative rho lies hundreds of lags out, so tier 2 (lags 64..255) and the
     first tier-3 round beyond it decide the truncation lag."""
