@@ -212,3 +212,25 @@ def test_tier3_single_launch_and_listed_routes_agree_with_the_oracle(ctx, oracle
         assert np.array_equal(goty[k], expy[k]), k
     for k in ("ess_bulk", "ess_tail", "rhat"):
         assert np.allclose(goty[k], expy[k], rtol=1e-9, atol=0), k
+
+
+def test_two_valued_columns_hit_the_band_by_chance_and_still_match(ctx, oracle):
+    """Not a construction: 3 000 indicator-type columns (4 x 500 draws, half of every chain's draws one, shuffled).  z is
+    then +-w with chain means of zero up to rounding, every lag product an integer times w^2, and rho is zero up to round-off
+    at the deciding lag of a few columns in a hundred -- its sign in the reference is whatever its left-to-right sums
+    leave.  Every integer term count must equal the oracle's (the reference's algorithm bit for bit), and the guard must
+    have run."""
+    rng = np.random.default_rng(2024)
+    P, C, N = 3000, 4, 500
+    base = np.concatenate([np.zeros(N // 2), np.ones(N // 2)])
+    x = np.stack([rng.permutation(base) for _ in range(P * C)]).reshape(P, C, N)
+    x[::3] *= 2.5                                        # other value pairs: the ranks are what matters
+    x[1::3] -= 7.0
+    exp = oracle.summarize_mt(x, "pcn")
+    before = ctx.rho_guard_count()
+    got = ctx.summarize(x, "pcn")
+    assert ctx.rho_guard_count() - before >= 5           # a few dozen columns in the band (seeded: deterministic)
+    for k in ("lag_bulk", "lag_tail"):
+        assert np.array_equal(got[k], exp[k]), (k, np.flatnonzero(got[k] != exp[k])[:10])
+    for k in ("ess_bulk", "ess_tail", "rhat"):
+        assert np.allclose(got[k], exp[k], rtol=1e-9, atol=0, equal_nan=True), k

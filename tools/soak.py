@@ -23,14 +23,15 @@ while time.time() < t_end:
     batch = []
     for _ in range(int(rng.integers(3, 14))):
         C = int(rng.choice([1, 2, 4, 4, 4, 10]))
-        N = int(rng.choice([1, 2, 7, 100, 1000, 1000, 2500, 4097, 10000, 30000]))
+        N = int(rng.choice([1, 2, 7, 100, 1000, 1000, 2500, 4097, 10000, 30000, 60000]))
         P = int(rng.integers(1, 40 if N <= 10000 else 6))
-        kind = rng.integers(0, 5)
+        kind = rng.integers(0, 6)
         x = rng.normal(size=(P, C, N))
         if kind == 1: x = np.round(x, 1)
         if kind == 2: x = np.cumsum(x, axis=2) * 0.02 + rng.normal(size=(P, C, N))
         if kind == 3: x[0] = 3.25
         if kind == 4: x = x.astype(np.float32)
+        if kind == 5: x = np.sign(x) * (1.0 + (np.arange(P) % 3)[:, None, None])      # two-valued columns: rho exactly zero now and then (guard band)
         layout = "pcn" if rng.integers(0, 3) else "cnp"
         if layout == "cnp": x = np.ascontiguousarray(np.transpose(x, (1, 2, 0)))
         batch.append((x, layout))
