@@ -371,6 +371,9 @@ int64_t mcr_fileset_names(const mcr_fileset* fs, char* buf, int64_t cap);
 #define MCR_FS_PH_TOTAL 7
 #define MCR_FS_PHASES 8
 int mcr_fileset_phases(const mcr_fileset* fs, double* ms, int cap);
+/* How many tensors (kernel pipelines) the files of the set were summarised as: files of one (chains, draws) shape that sit
+ * next to each other in the call's arena -- ordered by the chain count the footers' column statistics suggest -- are one. */
+int mcr_fileset_jobs(const mcr_fileset* fs);
 void mcr_fileset_free(mcr_fileset* fs);
 
 #ifdef __cplusplus

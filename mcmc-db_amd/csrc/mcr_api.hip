@@ -2477,7 +2477,7 @@ int mcr_gather_rows_dev(mcr_ctx* ctx, const double* src_dev, int64_t P, int64_t 
 
 struct mcr_fileset {
     double phase_ms[MCR_FS_PHASES] = {0};
-    int n_q = 0;
+    int n_q = 0, n_jobs = 0;
     struct Entry {
         std::vector<std::string> names;
         i64 C = 0, N = 0;
@@ -2602,8 +2602,18 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             }
             if (pl.chain < 0 || pl.draw < 0) { hipStreamSynchronize(ctx->stream); return fail(ctx, MCR_EINVAL, "%s: no chain / draw columns", paths[i]); }
             pl.M = f.num_rows;
-            pl.off = arena; arena += pl.cols.size() * (size_t)pl.M * 8;
             pl.ioff = ids; ids += (size_t)2 * (size_t)pl.M * 8;
+        }
+        // arena order = path order.  Measured in round 4 on the packaged corpus (five tensors as the files come: statistics
+        // phase 1.18 - 1.20 ms): files of one hinted shape laid next to each other (two tensors): 1.42 - 1.48 ms; tensors capped
+        // at 160 / 100 / 60 / 30 parameters (6 / 8 / 11 / 20 tensors): 1.29 / 1.33 / 1.40 / 1.90 ms; every tensor forked over
+        // two streams: 1.31 - 1.34 ms.  The real draws send a few pairs per model into tiers 2 and 3, whose latency-bound
+        // launches hide behind the other jobs' kernels on the other lanes; a handful of uneven jobs does that best.
+        std::vector<int> order((size_t)n_paths);
+        for (int i = 0; i < n_paths; ++i) {
+            order[(size_t)i] = i;
+            Plan& pl = plan[(size_t)i];
+            pl.off = arena; arena += pl.cols.size() * (size_t)pl.M * 8;
         }
         // 2. one batched decode into the arena ([P][M] per file, packed) + chain / draw ids behind it
         const size_t ids_base = align_up(arena, 256);
@@ -2680,20 +2690,21 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
         }
         struct Job { int first, count; i64 C, N, P; };
         std::vector<Job> jobs;
-        for (int i = 0; i < n_paths; ++i) {
-            const Plan& pl = plan[(size_t)i];
+        for (int oi = 0; oi < n_paths; ++oi) {             // (first / count index `order`, the arena's sequence of files)
+            const Plan& pl = plan[(size_t)order[(size_t)oi]];
             if (pl.cols.empty()) continue;
             const i64 Cj = diagnostics ? pl.C : 1, Nj = diagnostics ? pl.N : pl.M;
             if (!jobs.empty()) {
                 Job& j = jobs.back();
-                const Plan& last = plan[(size_t)(j.first + j.count - 1)];
-                if (j.first + j.count == i && j.C == Cj && j.N == Nj && last.off + last.cols.size() * (size_t)last.M * 8 == pl.off) {
+                const Plan& last = plan[(size_t)order[(size_t)(j.first + j.count - 1)]];
+                if (j.first + j.count == oi && j.C == Cj && j.N == Nj && last.off + last.cols.size() * (size_t)last.M * 8 == pl.off) {
                     ++j.count; j.P += (i64)pl.cols.size();
                     continue;
                 }
             }
-            jobs.push_back(Job{i, 1, Cj, Nj, (i64)pl.cols.size()});
+            jobs.push_back(Job{oi, 1, Cj, Nj, (i64)pl.cols.size()});
         }
+        fs->n_jobs = (int)jobs.size();
         // per-job staging of the results (a job spans files; scattered back below)
         constexpr int NF = MCR_FS_FIELDS;
         std::vector<std::vector<double>> jf(jobs.size() * NF);
@@ -2717,7 +2728,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             }
             if (ctx->n_inflight >= MCR_MAX_INFLIGHT) err = wait_one_impl(ctx);
             if (!err)
-                err = enqueue_impl(ctx, base + plan[(size_t)j.first].off, MCR_F64, j.C, j.N, j.P, j.N, 1, j.C * j.N,
+                err = enqueue_impl(ctx, base + plan[(size_t)order[(size_t)j.first]].off, MCR_F64, j.C, j.N, j.P, j.N, 1, j.C * j.N,
                                    diagnostics ? min_chains : 1, quantiles, n_q, &o);
             if (err) memcpy(keep, ctx->err, sizeof keep);
         }
@@ -2733,8 +2744,8 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
                 }
         for (size_t k = 0; k < jobs.size(); ++k) {
             size_t p0 = 0;
-            for (int i = jobs[k].first; i < jobs[k].first + jobs[k].count; ++i) {
-                mcr_fileset::Entry& e = fs->files[(size_t)i];
+            for (int oi = jobs[k].first; oi < jobs[k].first + jobs[k].count; ++oi) {
+                mcr_fileset::Entry& e = fs->files[(size_t)order[(size_t)oi]];
                 const size_t P = e.names.size();
                 for (int q = 0; q < NF; ++q) {
                     const size_t w = q == MCR_FS_Q ? (size_t)n_q : 1;
@@ -2803,6 +2814,7 @@ int64_t mcr_fileset_names(const mcr_fileset* fs, char* buf, int64_t cap)
     return need;
 }
 
+int mcr_fileset_jobs(const mcr_fileset* fs) { return fs ? fs->n_jobs : -1; }
 int mcr_fileset_phases(const mcr_fileset* fs, double* ms, int cap)
 {
     if (!fs || !ms || cap < 0) return -1;

@@ -127,6 +127,7 @@ SYMBOLS = {
     "mcr_fileset_param_name": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int64]),
     "mcr_fileset_field": (_dp, [C.c_void_p, C.c_int, C.c_int]),
     "mcr_fileset_phases": (C.c_int, [C.c_void_p, _dp, C.c_int]),
+    "mcr_fileset_jobs": (C.c_int, [C.c_void_p]),
     "mcr_fileset_export": (C.c_int64, [C.c_void_p, _dp, C.c_int64]),
     "mcr_fileset_names": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mcr_fileset_free": (None, [C.c_void_p]),

@@ -307,6 +307,7 @@ def _summarize_paths(ctx: "_ffi.Context", paths: list[str], min_chains: int, qs:
             ms = (C.c_double * len(FS_PHASES))()
             L.mcr_fileset_phases(fs, ms, len(FS_PHASES))
             phases.update(zip(FS_PHASES, (float(v) for v in ms)))
+            phases["jobs"] = int(L.mcr_fileset_jobs(fs))
         nq = len(qs)
         qkeys = [f"q{int(v * 100)}" for v in qs]
         nfiles = L.mcr_fileset_size(fs)

@@ -20,6 +20,7 @@ for _ in range(reps):
     t0 = time.perf_counter(); parquet.summarize_files(ctx, paths); wall_py.append((time.perf_counter() - t0) * 1e3)
 out = {"files": len(paths), "file_bytes": sum(p.stat().st_size for p in paths),
        "phases_ms_median": {k: round(statistics.median(r[k] for r in runs), 3) for k in runs[0]},
+       "io_threads": int(__import__("os").environ.get("MCR_IO_THREADS", "8")), "fork": __import__("os").environ.get("MCR_FORK", "1"),
        "c_call_plus_dicts_ms_median": round(statistics.median(wall_c), 3), "summarize_files_ms_median": round(statistics.median(wall_py), 3),
        "summarize_files_ms_min": round(min(wall_py), 3)}
 print(json.dumps(out))
