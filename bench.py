@@ -377,7 +377,7 @@ def leg_call_latency(ctx, t, host, got_pipelined: dict) -> dict:
             "validated": bool(same)}
 
 
-def leg_d_sweep(ctx, synth, orc, C: int, N: int, c1_ms: float | None) -> list[dict]:
+def leg_d_sweep(ctx, synth, orc, C: int, N: int) -> list[dict]:
     """north_star: throughput on synthetic (4 chains x 10 000 draws x D params).  Pipelined (8 calls in flight) and one
     synchronous call, D = 10 / 100 / 1000, each validated against the oracle on the calls that were timed."""
     out = []
@@ -735,7 +735,7 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
         lat = leg_call_latency(ctx, t, host, got)
         extras["sync_call_us"], extras["host_call_us"] = lat["sync_call_us"], lat["host_call_us"]
         extras["call_latency"] = lat
-        extras["d_sweep"] = leg_d_sweep(ctx, synth, orc, C, N, elapsed / a.steps * 1e3)
+        extras["d_sweep"] = leg_d_sweep(ctx, synth, orc, C, N)
         extras["configs"]["corpus_device"] = leg_corpus_device(ctx, _ffi, orc)
         cf = leg_corpus_files(ctx)
         if cf is not None:

@@ -12,7 +12,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
@@ -2487,11 +2486,10 @@ struct mcr_fileset {
 };
 
 namespace {
-struct MappedFile {
-    int fd = -1; void* map = MAP_FAILED; size_t len = 0; mcr_parquet* pq = nullptr;
-    ~MappedFile() {
+struct OpenFile {          // a draws file of mcr_summarize_files: descriptor, size, parsed metadata (its image lives in the pinned buffer)
+    int fd = -1; size_t len = 0; mcr_parquet* pq = nullptr;
+    ~OpenFile() {
         if (pq) mcr_parquet_close(pq);
-        if (map != MAP_FAILED) munmap(map, len);
         if (fd >= 0) close(fd);
     }
 };
@@ -2512,7 +2510,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
     clk::time_point t_prev = t_start;
     auto lap = [&](int k) { const clk::time_point now = clk::now(); phase[k] += std::chrono::duration<double, std::milli>(now - t_prev).count(); t_prev = now; };
     try {
-        std::vector<MappedFile> mf((size_t)n_paths);
+        std::vector<OpenFile> mf((size_t)n_paths);
         struct Plan { std::vector<int> cols; int chain = -1, draw = -1; i64 M = 0; size_t off = 0, ioff = 0; i64 C = 0, N = 0; };
         std::vector<Plan> plan((size_t)n_paths);
         size_t arena = 0, ids = 0;
@@ -2524,7 +2522,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
         //    HIP calls stay on the calling thread.
         std::vector<size_t> img_off((size_t)n_paths + 1, 0);
         for (int i = 0; i < n_paths; ++i) {
-            MappedFile& m = mf[(size_t)i];
+            OpenFile& m = mf[(size_t)i];
             m.fd = open(paths[i], O_RDONLY);
             struct stat st;
             if (m.fd < 0 || fstat(m.fd, &st) != 0) return fail(ctx, MCR_EINVAL, "cannot open %s", paths[i]);
@@ -2553,7 +2551,7 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             std::atomic<int> next{0};
             auto reader = [&]() {
                 for (int i; (i = next.fetch_add(1)) < n_paths;) {
-                    MappedFile& m = mf[(size_t)i];
+                    OpenFile& m = mf[(size_t)i];
                     auto bad = [&](int code, const std::string& msg) { frc[(size_t)i] = code; ferr[(size_t)i] = msg; };
                     try {
                         size_t got = 0;
