@@ -464,7 +464,13 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
     if (fused_tier3) {
         // the common case in one launch: list, products of the single round [256, n) and scan (k_tier3)
         const unsigned groups = (unsigned)((a.n - kLag2 + kLongGroup - 1) / kLongGroup);
-        const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
+        // slots = listed pairs worked on side by side.  Two for long chains (their lag groups already make dozens of
+        // workgroups, and a launch with nothing listed must stay cheap); short chains have only a few lag groups -- 3 for the
+        // packaged corpus' 1 000 draws, whose 57 models put 34 pairs on the list: 17 of them one after the other per slot was
+        // most of what real draws cost over synthetic ones (tools/corpus_kprof.py) -- so they get up to 16, ~64 workgroups in all.
+        unsigned slots = 64u / (groups ? groups : 1u);
+        slots = slots < (unsigned)kLongSlots ? (unsigned)kLongSlots : (slots > 16u ? 16u : slots);
+        if ((i64)slots > 2 * a.pc) slots = (unsigned)(2 * a.pc);
         LAUNCH(ctx, K_ACOV_LONG, k_tier3, dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB, a.M, a.d_off,
                a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, a.long_list,
                (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.chstate);
@@ -505,12 +511,14 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
                a.acov);
         slot_from = F;
     }
-    const unsigned slots = (unsigned)((2 * a.pc < kLongSlots) ? 2 * a.pc : kLongSlots);
     const unsigned scan_slots = (unsigned)((2 * a.pc < 16) ? 2 * a.pc : 16);      // one light workgroup per listed pair at a time
     for (i64 L0 = kLag2; L0 < a.n;) {
         const i64 L1 = (L0 < 16384) ? 16384 : L0 * 4;
         const i64 lend = (L1 < a.n) ? L1 : a.n;
         const unsigned groups = (unsigned)((lend - L0 + kLongGroup - 1) / kLongGroup);
+        unsigned slots = 64u / (groups ? groups : 1u);                              // as for k_tier3: ~64 workgroups when the round has few lag groups
+        slots = slots < (unsigned)kLongSlots ? (unsigned)kLongSlots : (slots > 16u ? 16u : slots);
+        if ((i64)slots > 2 * a.pc) slots = (unsigned)(2 * a.pc);
         LAUNCH(ctx, K_ACOV_LONG, (k_acov_long<256>), dim3(groups, slots), dim3(256), 0, (const double*)a.kA, (const double*)a.kB,
                a.M, a.d_off, a.C, a.n, L0, L1, (const unsigned*)a.long_count, (const unsigned*)a.long_list,
                (const double*)a.state, a.acov, slot_from);
@@ -2602,11 +2610,11 @@ int mcr_summarize_files(mcr_ctx* ctx, const char* const* paths, int n_paths, int
             pl.M = f.num_rows;
             pl.ioff = ids; ids += (size_t)2 * (size_t)pl.M * 8;
         }
-        // arena order = path order.  Measured in round 4 on the packaged corpus (five tensors as the files come: statistics
-        // phase 1.18 - 1.20 ms): files of one hinted shape laid next to each other (two tensors): 1.42 - 1.48 ms; tensors capped
-        // at 160 / 100 / 60 / 30 parameters (6 / 8 / 11 / 20 tensors): 1.29 / 1.33 / 1.40 / 1.90 ms; every tensor forked over
-        // two streams: 1.31 - 1.34 ms.  The real draws send a few pairs per model into tiers 2 and 3, whose latency-bound
-        // launches hide behind the other jobs' kernels on the other lanes; a handful of uneven jobs does that best.
+        // arena order = path order.  Measured in round 4 on the packaged corpus -- BEFORE k_tier3 got its extra slots for short
+        // chains, i.e. with 17 listed pairs per slot on the critical path of the statistics phase (1.18 - 1.20 ms then, 0.68 ms
+        // now; five tensors as the files come): files of one hinted shape laid next to each other (two tensors): 1.42 - 1.48 ms;
+        // tensors capped at 160 / 100 / 60 / 30 parameters (6 / 8 / 11 / 20 tensors): 1.29 / 1.33 / 1.40 / 1.90 ms; every tensor
+        // forked over two streams: 1.31 - 1.34 ms.
         std::vector<int> order((size_t)n_paths);
         for (int i = 0; i < n_paths; ++i) {
             order[(size_t)i] = i;
