@@ -460,8 +460,29 @@ __global__ __launch_bounds__(64) void k_pq_snappy(const unsigned char* __restric
             if ((u32)lane < pos && s_type == 0 && (u32)lane >= (u32)s_l + s_hdr)
                 ring[(s_opos + (u32)lane - (u32)s_l - s_hdr) & RM] = (unsigned char)c0;
             wave_sync();
-            // 4. copies, in stream order
             u64 cm = __ballot(isstart && type != 0);
+            // 4a. copies whose source lies wholly IN FRONT of this batch's output (and inside the ring) read bytes that are
+            //     final and write ranges of their own: they do not depend on one another and go all at once, one byte per
+            //     copy and step (round 4).  Stray 4-byte matches in otherwise incompressible pages are of this kind -- the
+            //     `Intercept` dictionary page of the packaged `diamonds` model is 1 868 of them between literals of a few
+            //     bytes, at offsets anywhere in Snappy's 64 KB window: one after the other, two LDS round trips each, that
+            //     page took 0.81 ms against 45 us for its literal-only neighbours, and the launch waits for its slowest page
+            //     (tools/pq_classes.py).
+            {
+                const bool indep = isstart && type != 0 && opos - off + olen <= op && off <= (u32)(kRing - kBatchOut);
+                const u64 im = __ballot(indep);
+                if (im & (im - 1)) {                                         // two or more
+                    const u32 mylen = indep ? olen : 0u;
+                    for (u32 i2 = 0;; ++i2) {
+                        const bool act = i2 < mylen;
+                        if (!__ballot(act)) break;
+                        if (act) ring[(opos + i2) & RM] = ring[(opos - off + i2) & RM];
+                    }
+                    cm &= ~im;
+                    wave_sync();
+                }
+            }
+            // 4b. the others, in stream order
             while (cm) {
                 const u32 s_c = (u32)__builtin_ctzll(cm);
                 cm &= cm - 1;

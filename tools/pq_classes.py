@@ -32,3 +32,24 @@ f = files[0]
 for pg in f.pages():
     if f.column_names[pg["column"]] in ("chain", "draw") or pg["column"] == 2:
         print(f.column_names[pg["column"]], {k: pg[k] for k in ("kind", "encoding", "compressed_size", "uncompressed_size", "num_values")})
+
+# which files' parameter columns are slow, and what their pages look like
+rows = []
+for f in files:
+    reqs, off = [], 0
+    for i, n in enumerate(f.column_names):
+        if n not in ("chain", "draw"):
+            reqs.append((f, i, MCR_PQ_F64, buf.ptr.value + off)); off += f.num_rows * 8
+    parquet.decode(ctx, reqs)
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(3):
+        parquet.decode(ctx, reqs)
+    pr = ctx.profile_get(); ctx.profile(False)
+    us = pr["k_pq_snappy"]["total_ms"] / pr["k_pq_snappy"]["launches"] * 1e3
+    rows.append((us, f.path.name, len(reqs)))
+rows.sort(reverse=True)
+print("slowest files (parameter columns only):", [(round(u), n[:40], k) for u, n, k in rows[:6]], "fastest:", [(round(u), n[:30]) for u, n, k in rows[-3:]])
+slow = [f for f in files if f.path.name == rows[0][1]][0]
+pg = [p for p in slow.pages() if slow.column_names[p["column"]] not in ("chain", "draw")]
+pg.sort(key=lambda p: p["compressed_size"] / max(p["uncompressed_size"], 1))
+print("its most compressible pages:", [(slow.column_names[p["column"]], p["kind"], p["compressed_size"], p["uncompressed_size"], p["num_values"]) for p in pg[:6]])
