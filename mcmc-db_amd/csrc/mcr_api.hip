@@ -988,7 +988,9 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                 a.do_diag = do_diag;
                 // (a graph capture or the per-kernel event pairs of the profiling mode keep the single stream)
                 a.fork = ctx->fork_lone && ctx->n_inflight == 0 && !ctx->prof && !ctx->graph_on && P <= pcmax &&
-                         (double)M * (double)pc <= 8e6;
+                         (double)M * (double)pc >= 2e6 && (double)M * (double)pc <= 8e6;    // kernels long enough to be worth
+                                                   // three more launches and two event waits (measured: C1 4 M param-draws 306 -> 288 us,
+                                                   // 10 x 1000 x 45 149 -> 166, 4 x 1000 x 10 124 -> 133), short enough not to fill the chip
                 a.fft = fp; a.tw1 = tw1; a.tw2 = tw2;
                 if (fp.on) {
                     const size_t Nf = (size_t)1 << fp.logN;

@@ -355,7 +355,7 @@ def test_lone_calls_fork_and_pipelined_calls_do_not_and_both_agree(monkeypatch):
     forked = _ffi.Context(0)
     rng = np.random.default_rng(4)
     try:
-        shapes = [(4, 10000, 12), (10, 1000, 45), (4, 1000, 3), (2, 50, 5), (4, 30000, 2)]
+        shapes = [(4, 10000, 60), (10, 1000, 250), (4, 1000, 3), (2, 50, 5), (4, 30000, 20)]      # forks from 2 M param-draws up
         xs = [synth.c1_model(C, N, P, seed=5 + i) for i, (C, N, P) in enumerate(shapes)]
         xs.append(np.cumsum(rng.normal(size=(6, 4, 5000)), axis=2) * 0.01)          # tier 3 behind the join
         for x in xs:
