@@ -409,6 +409,43 @@ def leg_d_sweep(ctx, synth, orc, C: int, N: int) -> list[dict]:
     return out
 
 
+def leg_sticky(ctx, orc, C: int, N: int, P: int) -> dict:
+    """The C1 shape with STICKY chains: every parameter an AR(1) walk with phi = 0.99 (integrated autocorrelation time ~ 200
+    draws, as hierarchical posteriors have), so that most (parameter, kind) pairs are still undecided at lag 256 and go
+    through tier 3 -- the synthetic C1 model of the headline stops at phi = 0.95 and never does.  Pipelined and lone call,
+    oracle on every parameter."""
+    from scipy.signal import lfilter
+    phi = 0.99
+    rng = np.random.default_rng(99)
+    x = lfilter([1.0], [1.0, -phi], rng.normal(size=(P, C, N)) * np.sqrt(1 - phi * phi), axis=2)
+    x += np.arange(P)[:, None, None]
+    t = ctx.upload(x, "pcn")
+
+    def run(k):
+        last = None
+        for _ in range(k):
+            if ctx.inflight >= 8:
+                ctx.wait_one()
+            last = ctx.enqueue(t)
+        ctx.wait()
+        return last
+    run(10)
+    ws = []
+    for _ in range(5):
+        ctx.sync(); t0 = time.perf_counter(); last = run(40); ctx.sync()
+        ws.append((time.perf_counter() - t0) / 40 * 1e3)
+    ms = statistics.median(ws)
+    sync_ms, _ = _median_ms(lambda: ctx.summarize(t), 10, ctx.sync)
+    got = last.result()
+    ok, worst = validate(got, orc.summarize_mt(x, "pcn"))
+    t.free()
+    lags = np.concatenate([got["lag_bulk"], got["lag_tail"]])
+    return {"workload": f"{C}x{N}x{P} f64, every parameter AR(1) with phi = {phi} (sticky chains: tiers 2 and 3 of the ESS lags)",
+            "pairs_beyond_lag_255": int((lags > 255).sum()), "pairs": int(lags.size), "max_truncation_lag": int(lags.max()),
+            "ms_per_call_pipelined": round(ms, 4), "param_draws_per_s": C * N * P / (ms * 1e-3), "sync_call_us": round(sync_ms * 1e3, 1),
+            "validated": ok, "max_rel_err": worst, "validation": "oracle on all parameters (integer truncation lags exact)"}
+
+
 def leg_corpus_device(ctx, _ffi, orc, steps: int = 20) -> dict:
     """BASELINE config 2, device-resident: the 57 packaged model shapes (synthetic draws), same-shape models batched."""
     from mcmc_ref_hip import corpus
@@ -736,6 +773,7 @@ def c1_bench(a, ctx, ranks: Ranks, _ffi, synth):
         extras["sync_call_us"], extras["host_call_us"] = lat["sync_call_us"], lat["host_call_us"]
         extras["call_latency"] = lat
         extras["d_sweep"] = leg_d_sweep(ctx, synth, orc, C, N)
+        extras["configs"]["sticky_c1"] = leg_sticky(ctx, orc, C, N, P)
         extras["configs"]["corpus_device"] = leg_corpus_device(ctx, _ffi, orc)
         cf = leg_corpus_files(ctx)
         if cf is not None:

@@ -466,7 +466,10 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
     if (pk == 0 && threadIdx.x == 0) long_count[0] = 0u;     // k_long_list (a later launch on this stream) sets the real length
-    if (pair_done != nullptr && threadIdx.x == 0) pair_done[pk] = 0u;  // k_tier3: lag groups that have finished this pair
+    if (pair_done != nullptr && threadIdx.x == 0) {        // k_tier3's per-pair words [3][2 P]: lag groups finished in round A, in round B, decided in round A
+        const i64 npk = 2 * P;
+        pair_done[pk] = 0u; pair_done[npk + pk] = 0u; pair_done[2 * npk + pk] = 0u;
+    }
 
     double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
     for (int c = w; c < C; c += W) {
@@ -867,7 +870,7 @@ struct ScanLds {
 // The scan of one listed pair over the lags [L0, lend).  All 256 threads call it.  z: the pair's rank codes (time order);
 // chst: its chains' state records.  mark: set state[pk][3] when the pair is decided (the listed route's rounds test it;
 // k_tier3 must NOT -- its workgroups build their lists from that word while other workgroups scan: ADVICE r3).
-__device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64 lend, double* __restrict__ state,
+__device__ __forceinline__ bool long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64 lend, double* __restrict__ state,
                                                double* __restrict__ acov, double* __restrict__ res, i64 P,
                                                const u32* __restrict__ z, const double* __restrict__ ztab, i64 M,
                                                double* __restrict__ chst, const i64* __restrict__ off, double band,
@@ -929,6 +932,7 @@ __device__ __forceinline__ void long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
         }
     }
     __syncthreads();
+    return first < lend || lend >= n;          // decided (uniform over the workgroup)
 }
 
 __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i64 L1,
@@ -961,17 +965,26 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
 // (first negative rho with the guard band, ordered prefix sum).  Three launches of round 2 -- list, products, scan --
 // in one; the fences are paid by workgroups that have a listed pair to work on, nobody else.
 constexpr int kTier3MaxPairs = 2048;
+constexpr int kTier3RoundA = 2048;       // lags of the first of k_tier3's two rounds on chains of more than kLag2 + this + 256 draws
 union Tier3Lds {
     LongLds<256> L;
     ScanLds S;
 };
+// One round of lags [L0, min(L1, n)).  Chains up to kLag2 + kTier3RoundA + 256 draws take ONE launch over [kLag2, n); longer
+// ones (up to 16 384) two: round A over [kLag2, kLag2 + kTier3RoundA), whose scan either decides a pair (first negative rho
+// found: results written, `mark[pk]` set) or leaves its partial sums in `state`, and round B over the rest for the pairs
+// round A left open (`skip` = round A's marks).  Round 4: with one round over all n - 256 lags a parameter whose walk ends
+// at lag 300 paid for 9 744 lags -- 122 such pairs of an AR(0.99) model at the C1 shape took 12 ms (tools/sticky_prof.py).
+// The list a launch works on must not change under it: round A lists on words nobody writes during it
+// (`more`, `state[.][3]`), its marks go to `mark`, which only round B reads.
 __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b, const double* __restrict__ dev_t, i64 M,
                                                const i64* __restrict__ off, int C, i64 n, const unsigned* __restrict__ more,
                                                double* __restrict__ state, double* __restrict__ acov, double* __restrict__ res,
                                                i64 P, double band, unsigned* __restrict__ guard_count,
                                                unsigned* __restrict__ pair_done, const u32* __restrict__ zb,
                                                const u32* __restrict__ zt, const double* __restrict__ ztab,
-                                               double* __restrict__ chstate)
+                                               double* __restrict__ chstate, i64 L0, i64 L1,
+                                               const unsigned* __restrict__ skip, unsigned* __restrict__ mark, unsigned groups)
 {
     __shared__ __attribute__((aligned(16))) Tier3Lds U;
     __shared__ unsigned short slist[kTier3MaxPairs];
@@ -981,7 +994,7 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
     unsigned count = 0;
     for (i64 k0 = 0; k0 < npk; k0 += 256) {
         const i64 pk = k0 + tid;
-        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0;
+        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0 && (skip == nullptr || skip[pk] == 0u);
         const unsigned long long bal = __ballot(listed);
         if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
         __syncthreads();
@@ -992,9 +1005,13 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
         __syncthreads();
     }
     if (count == 0) return;
-    const i64 lend = n;                                   // n <= 16 384: the round [kLag2, 16 384) covers every lag
-    const i64 lbase = kLag2 + (i64)kLongGroup * blockIdx.x;
-    for (unsigned slot = blockIdx.y; slot < count; slot += gridDim.y) {
+    const i64 lend = (L1 < n) ? L1 : n;
+    // The work items are (listed pair, group of 256 lags), pair-major, handed out round-robin over a FIXED number of
+    // workgroups: the grid does not grow with what might be listed (a launch with nothing listed -- the usual case -- costs
+    // its ~100 workgroups one pass over the marks), and whatever IS listed is spread over all of them.
+    for (unsigned item = blockIdx.x; item < count * groups; item += gridDim.x) {
+        const unsigned slot = item / groups;
+        const i64 lbase = L0 + (i64)kLongGroup * (item - slot * groups);
         const i64 pk = slist[slot];
         const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
         if (lbase < lend) acov_long_pair<256>(dev, off, C, n, lbase, lend, acov + pk * n, U.L);
@@ -1002,14 +1019,17 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
         if (tid == 0) {
             __threadfence();                              // agent-scope release of them
             const unsigned done = atomicAdd(&pair_done[pk], 1u);
-            s_last = (done + 1u == gridDim.x) ? 1u : 0u;
+            s_last = (done + 1u == groups) ? 1u : 0u;
             if (s_last) __threadfence();                  // acquire: the other groups' lags
         }
         __syncthreads();
-        // (mark = false: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list whenever it
-        //  starts -- a late workgroup used to see the pairs an early scan had already marked decided as unlisted: ADVICE r3)
-        if (s_last) long_scan_pair(pk, C, n, (i64)kLag2, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
-                                   chstate + pk * C * kChState, off, band, guard_count, false, U.S);
+        // (mark = false inside the scan: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list
+        //  whenever it starts -- a late workgroup used to see the pairs an early scan had already marked decided as unlisted)
+        if (s_last) {
+            const bool decided = long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
+                                                chstate + pk * C * kChState, off, band, guard_count, false, U.S);
+            if (decided && mark != nullptr && tid == 0) mark[pk] = 1u;
+        }
         __syncthreads();
     }
 }
