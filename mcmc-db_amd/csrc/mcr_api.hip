@@ -92,7 +92,7 @@ struct mcr_ctx {
     hipStream_t lane_aux[MCR_MAX_INFLIGHT] = {};      // second stream of a lane + its fork / join events (lone calls: run_pipeline)
     hipEvent_t lane_fork[MCR_MAX_INFLIGHT] = {}, lane_join[MCR_MAX_INFLIGHT] = {};
     bool fork_lone = true;                            // MCR_FORK=0: never fork
-    int t3_workgroups = 256;                          // MCR_T3_WG: workgroups of a k_tier3 launch (they share the (listed pair, lag group) items; half as many in round B)
+    int t3_workgroups = 256;                          // MCR_T3_WG: workgroups of a k_tier3 launch (they share the (listed pair, lag group) items)
     void* lane_ws[MCR_MAX_INFLIGHT] = {};
     size_t lane_ws_bytes[MCR_MAX_INFLIGHT] = {};
     int lane = 0, n_lanes = 4;
@@ -370,7 +370,7 @@ WsPlan plan_ws(i64 M, int C, bool ingest, bool ranks, i64 nstage)
                   (ranks ? (size_t)M * 32 + 1024 : 0) + (size_t)w.ntiles * kMomRec * 8 + 8 +
                   (size_t)2 * (size_t)(C > 0 ? C : 1) *
                       ((size_t)((nstage + kSeg - 1) / kSeg + 1) * (kSegRec + 64 * kMoreBlocks) + kChState) * 8 +
-                  (size_t)2 * (size_t)(nstage > 0 ? nstage : 1) * 8 + 2 * 4 + 6 * 4 + 2 * kPairState * 8 +
+                  (size_t)2 * (size_t)(nstage > 0 ? nstage : 1) * 8 + 2 * 4 + 2 * (kT3Stages + 1) * 4 + 2 * kPairState * 8 +
                   8 + 64;
     return w;
 }
@@ -398,7 +398,7 @@ struct PipeIn {
     double* acov;        // [pc][2][n] deviation products of tier 3 (lags >= 256), listed pairs only
     unsigned* long_count; // [1] number of pairs in the tier-3 list of this call
     unsigned* long_list;  // [2 pc]
-    unsigned* t3c;        // [3][2 pc] k_tier3: lag groups finished per pair in round A / in round B, decided in round A
+    unsigned* t3c;        // [kT3Stages + 1][2 pc] k_tier3: per pair and stage the finished lag groups (+ kT3Prev), then "decided"
     FftPlan fft;          // FFT tier for long chains (mcr_fft.hpp): buffers shared by the chunks of a call
     double2 *fft_A = nullptr, *fft_B = nullptr; double* fft_S = nullptr;
     double2 *tw1 = nullptr, *tw2 = nullptr;
@@ -464,32 +464,15 @@ int launch_diag(mcr_ctx* ctx, const PipeIn& a)
            (const double*)a.part, (int)a.ntiles, fused_tier3 ? 0 : 1, ctx->rho_band, ctx->guard_count);
     if (a.n <= kLag2) return MCR_OK;       // chains short enough to be decided by lag 255 never reach tier 3
     if (fused_tier3) {
-        // the common case: list, products and scan in one launch per round (k_tier3) -- one round over [256, n) for chains up
-        // to 2 560 draws, two beyond ([256, 2 304), then the rest for the pairs still open)
-        // The grid is a FIXED number of workgroups (MCR_T3_WG = 256; 128 in round B) that share the (listed pair, lag group)
-        // items round-robin.  Round 3 had ONE round over all n - 256 lags on a grid of (lag groups, 2 pairs at a time): the
-        // packaged corpus' 1 000-draw models -- 3 lag groups -- walked 17 of their 34 listed pairs one after the other per slot
-        // (most of what real draws cost over synthetic ones: statistics of the files path 1.18 -> 0.67 ms,
-        // tools/corpus_kprof.py), and an AR(0.99) model at the C1 shape -- 122 of 200 pairs listed, walks ending by lag 1 673 --
-        // paid for all 9 744 lags of every pair, two pairs at a time: 12 ms for that launch, 6.7 ms per pipelined call; now
-        // 0.45 + 0.45 ms and 0.88 ms (tools/sticky_prof.py; MCR_T3_WG 64 / 128 / 256 / 512: 2.0 / 1.19 / 0.88 / 0.78 ms).  With
-        // nothing listed -- the synthetic C1 model -- every workgroup leaves after compacting the marks; the second launch
-        // costs the pipelined C1 step 0.1555 -> 0.1578 - 0.1585 ms.
-        auto t3_round = [&](i64 L0, i64 L1, unsigned* counters, const unsigned* skip, unsigned* mark, int wg_max) -> int {
-            const i64 lend = (L1 < a.n) ? L1 : a.n;
-            const unsigned groups = (unsigned)((lend - L0 + kLongGroup - 1) / kLongGroup);
-            const i64 most = 2 * a.pc * (i64)groups;                       // work items if every pair were listed
-            const unsigned wgs = (unsigned)(most < (i64)wg_max ? most : (i64)wg_max);
-            LAUNCH(ctx, K_ACOV_LONG, k_tier3, dim3(wgs), dim3(256), 0, (const double*)a.kA, (const double*)a.kB, a.M, a.d_off,
-                   a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, counters,
-                   (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.chstate, L0, L1, skip, mark, groups);
-            return MCR_OK;
-        };
-        const i64 LA = kLag2 + kTier3RoundA;
-        if (a.n <= LA + kLongGroup) return t3_round(kLag2, a.n, a.t3c, nullptr, nullptr, ctx->t3_workgroups);
-        const int rc = t3_round(kLag2, LA, a.t3c, nullptr, a.t3c + 4 * a.pc, ctx->t3_workgroups);
-        if (rc) return rc;
-        return t3_round(LA, a.n, a.t3c + 2 * a.pc, a.t3c + 4 * a.pc, nullptr, ctx->t3_workgroups / 2);      // (seldom has anything to do)
+        // the common case in ONE launch: list, products of the lags [256, n) stage by stage, scans (k_tier3); a fixed number
+        // of workgroups (MCR_T3_WG) shares the (listed pair, lag group) items
+        const i64 groups = (a.n - kLag2 + kLongGroup - 1) / kLongGroup;
+        const i64 most = 2 * a.pc * groups;                                  // work items if every pair were listed
+        const unsigned wgs = (unsigned)(most < (i64)ctx->t3_workgroups ? most : (i64)ctx->t3_workgroups);
+        LAUNCH(ctx, K_ACOV_LONG, k_tier3, dim3(wgs), dim3(256), 0, (const double*)a.kA, (const double*)a.kB, a.M, a.d_off,
+               a.C, a.n, (const unsigned*)a.more, a.state, a.acov, a.d_res, a.pc, ctx->rho_band, ctx->guard_count, a.t3c,
+               (const u32*)a.zb, (const u32*)a.zt, (const double*)a.ztab, a.chstate);
+        return MCR_OK;
     }
     LAUNCH(ctx, K_DIAG2, k_long_list, dim3(1), dim3(1024), 0, (const unsigned*)a.more, (const double*)a.state, a.pc,
            a.long_count, a.long_list);
@@ -993,7 +976,7 @@ int enqueue_impl(mcr_ctx* ctx, const void* draws_dev, int dtype, i64 C, i64 N, i
                     a.acov = cv.take<double>((size_t)pc * 2 * (size_t)(N > 0 ? N : 1));
                     a.long_count = cv.take<unsigned>(1);
                     a.long_list = cv.take<unsigned>((size_t)pc * 2);
-                    a.t3c = cv.take<unsigned>((size_t)pc * 6);
+                    a.t3c = cv.take<unsigned>((size_t)pc * 2 * (kT3Stages + 1));
                 }
                 a.nstage = N > 0 ? N : 1;
                 a.ztab = ztab;
@@ -1542,7 +1525,7 @@ int mcr_diagnose_chains(mcr_ctx* ctx, const double* pooled, const int64_t* chain
         a.acov = cv.take<double>((size_t)2 * (size_t)(n > 0 ? n : 1));
         a.long_count = cv.take<unsigned>(1);
         a.long_list = cv.take<unsigned>(2);
-        a.t3c = cv.take<unsigned>(6);
+        a.t3c = cv.take<unsigned>(2 * (kT3Stages + 1));
     }
     a.nstage = nstage;
     rc = get_ztab(ctx, M, &a.ztab);

@@ -290,6 +290,11 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
     }
 }
 
+// k_tier3 walks the lags of a listed pair in STAGES of kT3StageGroups groups of 256 lags; per pair and stage one word counts
+// the finished groups (low bits) and carries kT3Prev once the stage in front has been scanned without a decision.
+constexpr int kT3StageGroups = 8, kT3Stages = 8;          // 8 x 8 x 256 lags cover chains up to 16 384 + 256 draws
+constexpr unsigned kT3Prev = 0x80000000u;
+
 // Per-chain state kept between the combine kernels.
 constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), the chain's LEFT-TO-RIGHT mean (NaN until a band lag needs it)
 // Per-pair scan state: rho_sum, terms, var_hat, decided (tier 3)
@@ -466,9 +471,10 @@ __global__ __launch_bounds__(64 * kCombineWaves) void k_diag_combine(const u32* 
     const int f_ess = kind ? R_ESS_TAIL : R_ESS_BULK;
     const int f_lag = kind ? R_LAG_TAIL : R_LAG_BULK;
     if (pk == 0 && threadIdx.x == 0) long_count[0] = 0u;     // k_long_list (a later launch on this stream) sets the real length
-    if (pair_done != nullptr && threadIdx.x == 0) {        // k_tier3's per-pair words [3][2 P]: lag groups finished in round A, in round B, decided in round A
+    if (pair_done != nullptr && threadIdx.x == 0) {        // k_tier3's per-pair words [kT3Stages + 1][2 P]: one per stage, then "decided"
         const i64 npk = 2 * P;
-        pair_done[pk] = 0u; pair_done[npk + pk] = 0u; pair_done[2 * npk + pk] = 0u;
+        pair_done[pk] = kT3Prev;                           // stage 0 has no stage in front of it to wait for
+        for (int st = 1; st <= kT3Stages; ++st) pair_done[st * npk + pk] = 0u;
     }
 
     double covsum = 0.0;   // lane l: sum over (this wave's) chains of sum_i (z_i - m)(z_{i+l} - m)
@@ -965,36 +971,44 @@ __global__ __launch_bounds__(256) void k_diag_long_scan(int C, i64 n, i64 L0, i6
 // (first negative rho with the guard band, ordered prefix sum).  Three launches of round 2 -- list, products, scan --
 // in one; the fences are paid by workgroups that have a listed pair to work on, nobody else.
 constexpr int kTier3MaxPairs = 2048;
-constexpr int kTier3RoundA = 2048;       // lags of the first of k_tier3's two rounds on chains of more than kLag2 + this + 256 draws
 union Tier3Lds {
     LongLds<256> L;
     ScanLds S;
 };
-// One round of lags [L0, min(L1, n)).  Chains up to kLag2 + kTier3RoundA + 256 draws take ONE launch over [kLag2, n); longer
-// ones (up to 16 384) two: round A over [kLag2, kLag2 + kTier3RoundA), whose scan either decides a pair (first negative rho
-// found: results written, `mark[pk]` set) or leaves its partial sums in `state`, and round B over the rest for the pairs
-// round A left open (`skip` = round A's marks).  Round 4: with one round over all n - 256 lags a parameter whose walk ends
-// at lag 300 paid for 9 744 lags -- 122 such pairs of an AR(0.99) model at the C1 shape took 12 ms (tools/sticky_prof.py).
-// The list a launch works on must not change under it: round A lists on words nobody writes during it
-// (`more`, `state[.][3]`), its marks go to `mark`, which only round B reads.
+// ONE launch for the whole of tier 3 on chains of at most 16 384 draws and at most kTier3MaxPairs pairs per chunk -- what
+// every call of the C1 shape and of the packaged corpus takes, with nothing listed more often than not.  grid: a FIXED number
+// of workgroups (MCR_T3_WG), block 256.
+//   * Every workgroup compacts the tier-3 marks of the 2 P pairs into its own LDS in ascending pair order (the list
+//     k_long_list would build; with nothing listed it is done after one pass over the marks).
+//   * The work items are (listed pair, group of 256 lags), handed out round-robin, STAGE by stage: a stage is
+//     kT3StageGroups = 8 groups = 2 048 lags, and all items of stage s come before any of stage s + 1.
+//   * The reference's walk stops at the first negative rho, so a pair's lags are scanned stage by stage, each scan as
+//     soon as (a) the stage's products are complete and (b) the stage in front has been scanned without a decision.  Both
+//     events are atomics on the pair's word of that stage -- the finisher of a group adds 1, the scanner of the stage in
+//     front ORs in kT3Prev -- and whichever comes second sees the other in the value it gets back and runs the scan:
+//     exactly once, nobody waits for anybody.  A scan that finds the first negative rho (or reaches the chain's end)
+//     writes the pair's results and sets its `decided` word; items of later stages look at that word first and skip.
+//   Round 3 computed all n - 256 lags of every listed pair, two pairs at a time: 122 pairs of an AR(0.99) model at the C1
+//   shape -- walks that end by lag 1 673 -- took 12 ms, a pipelined call 6.7 ms; the packaged corpus' 34 listed pairs went
+//   17 to a slot (tools/sticky_prof.py, tools/corpus_kprof.py).  The list a launch works on does not change under it
+//   (ADVICE r3): it is built from `more` and `state[.][3]`, which nobody writes here.
 __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b, const double* __restrict__ dev_t, i64 M,
                                                const i64* __restrict__ off, int C, i64 n, const unsigned* __restrict__ more,
                                                double* __restrict__ state, double* __restrict__ acov, double* __restrict__ res,
                                                i64 P, double band, unsigned* __restrict__ guard_count,
-                                               unsigned* __restrict__ pair_done, const u32* __restrict__ zb,
+                                               unsigned* __restrict__ words, const u32* __restrict__ zb,
                                                const u32* __restrict__ zt, const double* __restrict__ ztab,
-                                               double* __restrict__ chstate, i64 L0, i64 L1,
-                                               const unsigned* __restrict__ skip, unsigned* __restrict__ mark, unsigned groups)
+                                               double* __restrict__ chstate)
 {
     __shared__ __attribute__((aligned(16))) Tier3Lds U;
     __shared__ unsigned short slist[kTier3MaxPairs];
-    __shared__ unsigned s_wtot[4], s_last;
+    __shared__ unsigned s_wtot[4], s_flag;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const i64 npk = 2 * P;
     unsigned count = 0;
     for (i64 k0 = 0; k0 < npk; k0 += 256) {
         const i64 pk = k0 + tid;
-        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0 && (skip == nullptr || skip[pk] == 0u);
+        const bool listed = pk < npk && more[pk] != 0u && state[pk * kPairState + 3] == 0.0;
         const unsigned long long bal = __ballot(listed);
         if (lane == 0) s_wtot[w] = (unsigned)__popcll(bal);
         __syncthreads();
@@ -1005,32 +1019,53 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
         __syncthreads();
     }
     if (count == 0) return;
-    const i64 lend = (L1 < n) ? L1 : n;
-    // The work items are (listed pair, group of 256 lags), pair-major, handed out round-robin over a FIXED number of
-    // workgroups: the grid does not grow with what might be listed (a launch with nothing listed -- the usual case -- costs
-    // its ~100 workgroups one pass over the marks), and whatever IS listed is spread over all of them.
-    for (unsigned item = blockIdx.x; item < count * groups; item += gridDim.x) {
-        const unsigned slot = item / groups;
-        const i64 lbase = L0 + (i64)kLongGroup * (item - slot * groups);
-        const i64 pk = slist[slot];
-        const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
-        if (lbase < lend) acov_long_pair<256>(dev, off, C, n, lbase, lend, acov + pk * n, U.L);
-        __syncthreads();                                  // every store of this workgroup's lags is issued
-        if (tid == 0) {
-            __threadfence();                              // agent-scope release of them
-            const unsigned done = atomicAdd(&pair_done[pk], 1u);
-            s_last = (done + 1u == groups) ? 1u : 0u;
-            if (s_last) __threadfence();                  // acquire: the other groups' lags
+    unsigned* decided = words + (i64)kT3Stages * npk;
+    const int groups = (int)((n - kLag2 + kLongGroup - 1) / kLongGroup);            // <= kT3Stages * kT3StageGroups (n <= 16 384)
+    const int nstages = (groups + kT3StageGroups - 1) / kT3StageGroups;
+    auto stage_groups = [&](int st) { const int left = groups - st * kT3StageGroups; return left < kT3StageGroups ? left : kT3StageGroups; };
+    for (int st = 0; st < nstages; ++st) {
+        const unsigned cnt = (unsigned)stage_groups(st);
+        for (unsigned item = blockIdx.x; item < count * cnt; item += gridDim.x) {
+            const unsigned slot = item / cnt;
+            const i64 pk = slist[slot];
+            if (tid == 0) s_flag = atomicOr(&decided[pk], 0u);                       // (read at the L2: another workgroup sets it)
+            __syncthreads();
+            const bool skip = s_flag != 0u;
+            __syncthreads();
+            if (skip) continue;
+            const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
+            const i64 lbase = kLag2 + (i64)kLongGroup * (st * kT3StageGroups + (int)(item - slot * cnt));
+            acov_long_pair<256>(dev, off, C, n, lbase, n, acov + pk * n, U.L);
+            __syncthreads();                                  // every store of this workgroup's lags is issued
+            if (tid == 0) {
+                __threadfence();                              // agent-scope release of them
+                const unsigned old = atomicAdd(&words[(i64)st * npk + pk], 1u);
+                s_flag = ((old & 0xFFFFu) + 1u == cnt && (old & kT3Prev)) ? 1u : 0u;   // last group of the stage, and the stage in front is through
+                if (s_flag) __threadfence();                  // acquire: the other groups' lags, the scan state of the stage in front
+            }
+            __syncthreads();
+            int sc = st;                                      // this workgroup scans stage sc, and the following ones while they are ready
+            while (s_flag) {
+                const i64 L0 = kLag2 + (i64)kLongGroup * kT3StageGroups * sc;
+                const i64 L1 = L0 + (i64)kLongGroup * kT3StageGroups;
+                const i64 lend = (L1 < n) ? L1 : n;
+                // (mark = false: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list)
+                const bool done = long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
+                                                 chstate + pk * C * kChState, off, band, guard_count, false, U.S);
+                if (tid == 0) {
+                    if (done) { atomicExch(&decided[pk], 1u); s_flag = 0u; }
+                    else {                                    // hand the walk to stage sc + 1: scan it now if its products are complete
+                        __threadfence();                      // release: the partial sums in state[pk]
+                        const unsigned old = atomicOr(&words[(i64)(sc + 1) * npk + pk], kT3Prev);
+                        s_flag = ((old & 0xFFFFu) == (unsigned)stage_groups(sc + 1)) ? 1u : 0u;
+                        if (s_flag) __threadfence();
+                    }
+                }
+                __syncthreads();
+                ++sc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // (mark = false inside the scan: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list
-        //  whenever it starts -- a late workgroup used to see the pairs an early scan had already marked decided as unlisted)
-        if (s_last) {
-            const bool decided = long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
-                                                chstate + pk * C * kChState, off, band, guard_count, false, U.S);
-            if (decided && mark != nullptr && tid == 0) mark[pk] = 1u;
-        }
-        __syncthreads();
     }
 }
 
