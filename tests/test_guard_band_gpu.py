@@ -234,3 +234,45 @@ def test_two_valued_columns_hit_the_band_by_chance_and_still_match(ctx, oracle):
         assert np.array_equal(got[k], exp[k]), (k, np.flatnonzero(got[k] != exp[k])[:10])
     for k in ("ess_bulk", "ess_tail", "rhat"):
         assert np.allclose(got[k], exp[k], rtol=1e-9, atol=0, equal_nan=True), k
+
+
+def test_tier3_stages_pairs_that_end_in_different_stages(ctx, oracle):
+    """k_tier3 walks a listed pair's lags in stages of 2 048 (round 4): a stage is scanned by whichever workgroup completes
+    the later of "its products are there" / "the stage in front is through", and later items skip decided pairs.  AR(1)
+    chains of 4 x 10 000 draws with phi from 0.9 to 0.9995 plus random walks end their walks before tier 3 and in its first
+    two stages; trends, a level shift and a walk on 4 x 16 000 draws (62 lag groups = 8 stages) in the second and third.
+    Many listed pairs against the launch's 256 workgroups, several calls in flight, repeated: lags exact every time."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(123)
+    phis = np.array([0.9, 0.97, 0.985, 0.99, 0.993, 0.996, 0.998, 0.999, 0.9993, 0.9995] * 2)
+    e = rng.normal(size=(len(phis), 4, 10000)) * np.sqrt(1 - phis * phis)[:, None, None]
+    x = np.stack([lfilter([1.0], [1.0, -p], e[i], axis=1) for i, p in enumerate(phis)])
+    w = np.cumsum(rng.normal(size=(8, 4, 10000)), axis=2) * 0.01
+    w[4:] += rng.normal(size=(4, 4, 10000)) * 0.3
+    x = np.concatenate([x, w])
+    n = 16000
+    tt = np.arange(n) / n
+    y = np.empty((4, 4, n))
+    y[0] = 3 * tt + rng.normal(size=(4, n)) * 0.2
+    y[1] = np.where(tt < 0.5, -1.0, 1.0) + rng.normal(size=(4, n)) * 0.3
+    y[2] = np.cumsum(rng.normal(size=(4, n)), axis=1) * 0.01
+    y[3] = np.cos(np.pi * tt) + rng.normal(size=(4, n)) * 0.1
+    seen = set()
+    for arr in (x, y):
+        exp = oracle.summarize_mt(arr, "pcn")
+        lags = np.concatenate([exp["lag_bulk"], exp["lag_tail"]])
+        seen |= set(((lags[lags > 255] - 256) // 2048).tolist()) | ({-1} if (lags <= 255).any() else set())
+        t = ctx.upload(arr, "pcn")
+        try:
+            for _ in range(3):
+                bufs = [ctx.enqueue(t) for _ in range(4)]
+                ctx.wait()
+                for b in bufs:
+                    g = b.result()
+                    for k in ("lag_bulk", "lag_tail"):
+                        assert np.array_equal(g[k], exp[k]), (k, g[k], exp[k])
+                    for k in ("ess_bulk", "ess_tail", "rhat"):
+                        assert np.allclose(g[k], exp[k], rtol=1e-9, atol=0), k
+        finally:
+            t.free()
+    assert {-1, 0, 1, 2}.issubset(seen), sorted(seen)
