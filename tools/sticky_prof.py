@@ -27,6 +27,6 @@ for phi, (C, N, P) in ((0.99, (4, 10000, 100)), (0.999, (4, 10000, 100)), (0.99,
             ctx.enqueue(t2)
         ctx.wait()
     run(20); t0 = time.perf_counter(); run(100); dt = (time.perf_counter() - t0) / 100
-    print(f"T3_WG={os.environ.get('MCR_T3_WG', '128')} phi={phi} {C}x{N}x{P}: pairs beyond lag 255: {(lags > 255).sum()} of {lags.size}, max lag {lags.max()}; "
+    print(f"T3_WG={os.environ.get('MCR_T3_WG', '256')} phi={phi} {C}x{N}x{P}: pairs beyond lag 255: {(lags > 255).sum()} of {lags.size}, max lag {lags.max()}; "
           f"pipelined {dt*1e6:.0f} us/call; alone: " + "  ".join(f"{k[2:]}={v['total_ms']/v['launches']*1e3:.0f}" for k, v in sorted(pr.items(), key=lambda kv: -kv[1]['total_ms'])[:6]), flush=True)
     c1.close(); ctx.close()
