@@ -292,8 +292,16 @@ __global__ __launch_bounds__(NT) void k_acov_seg(const u32* __restrict__ zb, con
 
 // k_tier3 walks the lags of a listed pair in STAGES of kT3StageGroups groups of 256 lags; per pair and stage one word counts
 // the finished groups (low bits) and carries kT3Prev once the stage in front has been scanned without a decision.
-constexpr int kT3StageGroups = 8, kT3Stages = 8;          // 8 x 8 x 256 lags cover chains up to 16 384 + 256 draws
+constexpr int kT3StageGroups = 8, kT3Stages = 9;          // stages of 2, 6, 8, 8, ... groups: 64 groups cover chains up to 16 384 + 256 draws
 constexpr unsigned kT3Prev = 0x80000000u;
+// first lag group of stage st: most walks that reach tier 3 at all end within a few hundred lags of it, so the first stage
+// is short (lags 256 .. 767), the second takes the rest of the first 2 048, the others 2 048 each
+// (chains of up to 2 304 draws -- 8 groups at most, the packaged corpus has 3 -- are ONE stage: with so few items per pair
+//  a second stage only adds a hand-over, measured 71 -> 120 us on 13 listed pairs of 10 x 1 000 draws)
+__host__ __device__ constexpr int t3_stage_first(int st, int groups)
+{
+    return groups <= kT3StageGroups ? (st == 0 ? 0 : groups) : (st == 0 ? 0 : (st == 1 ? 2 : kT3StageGroups * (st - 1)));
+}
 
 // Per-chain state kept between the combine kernels.
 constexpr int kChState = 6;   // mean, S, constant flag, head(kLag1), tail(kLag1), the chain's LEFT-TO-RIGHT mean (NaN until a band lag needs it)
@@ -980,8 +988,8 @@ union Tier3Lds {
 // of workgroups (MCR_T3_WG), block 256.
 //   * Every workgroup compacts the tier-3 marks of the 2 P pairs into its own LDS in ascending pair order (the list
 //     k_long_list would build; with nothing listed it is done after one pass over the marks).
-//   * The work items are (listed pair, group of 256 lags), handed out round-robin, STAGE by stage: a stage is
-//     kT3StageGroups = 8 groups = 2 048 lags, and all items of stage s come before any of stage s + 1.
+//   * The work items are (listed pair, group of 256 lags), handed out round-robin, STAGE by stage: stages of 2, 6, 8, 8, ...
+//     groups (lags 256 .. 767, .. 2 303, then 2 048 each), and all items of stage s come before any of stage s + 1.
 //   * The reference's walk stops at the first negative rho, so a pair's lags are scanned stage by stage, each scan as
 //     soon as (a) the stage's products are complete and (b) the stage in front has been scanned without a decision.  Both
 //     events are atomics on the pair's word of that stage -- the finisher of a group adds 1, the scanner of the stage in
@@ -1021,8 +1029,9 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
     if (count == 0) return;
     unsigned* decided = words + (i64)kT3Stages * npk;
     const int groups = (int)((n - kLag2 + kLongGroup - 1) / kLongGroup);            // <= kT3Stages * kT3StageGroups (n <= 16 384)
-    const int nstages = (groups + kT3StageGroups - 1) / kT3StageGroups;
-    auto stage_groups = [&](int st) { const int left = groups - st * kT3StageGroups; return left < kT3StageGroups ? left : kT3StageGroups; };
+    int nstages = 1;
+    while (t3_stage_first(nstages, groups) < groups) ++nstages;                             // <= kT3Stages
+    auto stage_groups = [&](int st) { const int a = t3_stage_first(st, groups), b = t3_stage_first(st + 1, groups); return (b < groups ? b : groups) - a; };
     for (int st = 0; st < nstages; ++st) {
         const unsigned cnt = (unsigned)stage_groups(st);
         for (unsigned item = blockIdx.x; item < count * cnt; item += gridDim.x) {
@@ -1034,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
             __syncthreads();
             if (skip) continue;
             const double* dev = ((pk & 1) ? dev_t : dev_b) + (pk >> 1) * M;
-            const i64 lbase = kLag2 + (i64)kLongGroup * (st * kT3StageGroups + (int)(item - slot * cnt));
+            const i64 lbase = kLag2 + (i64)kLongGroup * (t3_stage_first(st, groups) + (int)(item - slot * cnt));
             acov_long_pair<256>(dev, off, C, n, lbase, n, acov + pk * n, U.L);
             __syncthreads();                                  // every store of this workgroup's lags is issued
             if (tid == 0) {
@@ -1046,8 +1055,8 @@ __global__ __launch_bounds__(256) void k_tier3(const double* __restrict__ dev_b,
             __syncthreads();
             int sc = st;                                      // this workgroup scans stage sc, and the following ones while they are ready
             while (s_flag) {
-                const i64 L0 = kLag2 + (i64)kLongGroup * kT3StageGroups * sc;
-                const i64 L1 = L0 + (i64)kLongGroup * kT3StageGroups;
+                const i64 L0 = kLag2 + (i64)kLongGroup * t3_stage_first(sc, groups);
+                const i64 L1 = kLag2 + (i64)kLongGroup * t3_stage_first(sc + 1, groups);
                 const i64 lend = (L1 < n) ? L1 : n;
                 // (mark = false: state[pk][3] stays 0 for the whole launch, so every workgroup compacts the SAME list)
                 const bool done = long_scan_pair(pk, C, n, L0, lend, state, acov, res, P, ((pk & 1) ? zt : zb) + (pk >> 1) * M, ztab, M,
