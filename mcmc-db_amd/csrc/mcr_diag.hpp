@@ -894,6 +894,11 @@ __device__ __forceinline__ bool long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
     double* stp = state + pk * kPairState;
     const double vhat = stp[2];
     double* a = acov + pk * n;
+    // The products were written by OTHER workgroups of this launch (k_tier3: in stages, and this CU may have read a cache line
+    // that straddles a stage boundary -- acov[pk] is line-aligned only when n is a multiple of 16 -- while scanning the stage in
+    // front): they are read at agent scope, past the CU's own L1, whatever it holds.  (The acquire fence in front of a scan
+    // invalidates that L1 already; this makes the scan independent of it.)
+    auto ld = [&](i64 l) { return __hip_atomic_load(a + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const double den = (double)C * vhat;
     const double thr = band * den;
     i64 from = L0, first = lend;
@@ -905,13 +910,13 @@ __device__ __forceinline__ bool long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
         for (i64 l = from + tid; l < lend; l += 256) {
             // rho < band  <=>  acov < band * den * (n - l) (den > 0): no division in the search; where exactly the band's
             // top lies does not matter, every lag it catches is looked at again below
-            if (a[l] < thr * (double)(n - l)) { mine = l; break; }     // the thread's lags ascend: its first one below the band's top
+            if (ld(l) < thr * (double)(n - l)) { mine = l; break; }     // the thread's lags ascend: its first one below the band's top
         }
         if (mine < (long long)lend) atomicMin(&S.sfirst, mine);
         __syncthreads();
         first = (i64)S.sfirst;
         if (first >= lend) break;                                  // every remaining lag of the round is clearly positive
-        const double rho_f = (a[first] / (double)(n - first)) / den;
+        const double rho_f = (ld(first) / (double)(n - first)) / den;
         if (rho_f < -band || budget == 0) {                        // clearly negative (or out of budget: decided as it stands)
             if (!(rho_f < 0.0)) { from = first + 1; __syncthreads(); continue; }
             break;
@@ -930,7 +935,7 @@ __device__ __forceinline__ bool long_scan_pair(i64 pk, int C, i64 n, i64 L0, i64
     }
     __syncthreads();
     double s = 0.0;
-    for (i64 l = L0 + tid; l < first; l += 256) s += (a[l] / (double)(n - l)) / den;
+    for (i64 l = L0 + tid; l < first; l += 256) s += (ld(l) / (double)(n - l)) / den;
     s = block_sum<256>(s, S.red);
     if (tid == 0) {
         const double rho_sum = stp[0] + s;

@@ -276,3 +276,30 @@ def test_tier3_stages_pairs_that_end_in_different_stages(ctx, oracle):
         finally:
             t.free()
     assert {-1, 0, 1, 2}.issubset(seen), sorted(seen)
+
+
+@pytest.mark.parametrize("n", [4097, 6001, 9999, 12001])
+def test_tier3_stages_with_chain_lengths_that_are_not_multiples_of_16(ctx, oracle, n):
+    """The products of a listed pair live in acov[pair][n]: with n not a multiple of 16 a 128-byte cache line can hold the
+    last lags of one stage and the first of the next, which another workgroup writes later -- the scan reads them at agent
+    scope (and behind an acquire fence), never from a line its CU cached while scanning the stage in front.  Random walks
+    whose ESS walks cross several stages, many pairs, calls in flight on every lane, three times over."""
+    rng = np.random.default_rng(n)
+    x = np.cumsum(rng.normal(size=(24, 4, n)), axis=2) * 0.01
+    x[::3] += rng.normal(size=(8, 4, n)) * 0.2
+    exp = oracle.summarize_mt(x, "pcn")
+    lags = np.concatenate([exp["lag_bulk"], exp["lag_tail"]])
+    assert (lags > 768).sum() >= 10 and ((lags > 2304).sum() >= 1 or n < 6000), lags      # (4 097 draws: stages 1 and 2 only)
+    t = ctx.upload(x, "pcn")
+    try:
+        for _ in range(3):
+            bufs = [ctx.enqueue(t) for _ in range(8)]
+            ctx.wait()
+            for b in bufs:
+                g = b.result()
+                for k in ("lag_bulk", "lag_tail"):
+                    assert np.array_equal(g[k], exp[k]), (k, np.flatnonzero(g[k] != exp[k]))
+                for k in ("ess_bulk", "ess_tail", "rhat"):
+                    assert np.allclose(g[k], exp[k], rtol=1e-9, atol=0), k
+    finally:
+        t.free()
