@@ -386,12 +386,14 @@ def leg_d_sweep(ctx, synth, orc, C: int, N: int) -> list[dict]:
         t = ctx.upload(host, "pcn")
         steps = {10: 400, 100: 200, 1000: 40}[P]
 
+        ring = []                                   # result buffers of delivered calls, reused (as the headline's loop does)
+
         def run(k):
             last = None
             for _ in range(k):
                 if ctx.inflight >= 8:
-                    ctx.wait_one()
-                last = ctx.enqueue(t)
+                    ring.append(ctx.wait_one())
+                last = ctx.enqueue(t, bufs=ring.pop() if ring else None)
             ctx.wait()
             return last
         run(max(steps // 10, 4))
